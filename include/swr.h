@@ -1,0 +1,190 @@
+/*
+ * swr.h -- C ABI of the MI355X-native rasterizer backend (libswr_hip.so).
+ *
+ * Drop-in boundary for the raster hot path of OCSYT/SoftwareRenderer.  The
+ * reference has no FFI of its own: the C# host calls
+ * `Rasterizer.RenderMesh` directly with delegates and a MainWindow object.  Each
+ * entry point below names the reference interface it replaces (file:line under
+ * the C# repo); INTEGRATION.md shows the P/Invoke stub a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++/torch types; every function returns an
+ *    int status (SWR_OK = 0, negative = error) and never unwinds across the ABI.
+ *    swr_last_error() gives the text of the last failure on that context.
+ *  - matrices are 16 floats M11..M44, row-major, row-vector convention
+ *    (v' = v * M) exactly as System.Numerics.Matrix4x4 is laid out in memory.
+ *  - caller owns every input array for the duration of the call; retained meshes
+ *    and textures are copied to HBM and owned by the context until destroyed.
+ *  - draw calls are RECORDED in submission order under a context mutex and
+ *    executed on the GPU at swr_flush / swr_readback / any accessor that needs
+ *    pixels, so concurrent callers (Renderer.cs:444 Parallel.ForEach) are safe and
+ *    the result equals the serial schedule mesh 0,1,2... triangle 0,1,2...
+ *  - one context drives one GPU (one process per GPU); for multi-GPU frames each
+ *    rank owns a band of 16-pixel tile rows (swr_set_band) and the host gathers
+ *    the colour bands (RCCL) -- see softwarerenderer_amd/multigpu.py.
+ *  - there is NO CPU fallback: without a usable HIP device swr_create fails.
+ */
+#ifndef SWR_H
+#define SWR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWR_ABI_VERSION 1
+
+/* status codes */
+#define SWR_OK                 0
+#define SWR_ERR_INVALID_ARG   (-1)  /* C#: ArgumentException (Rasterizer.cs:71-74) / IndexOutOfRangeException */
+#define SWR_ERR_HIP           (-2)  /* a HIP runtime call failed */
+#define SWR_ERR_OOM           (-3)  /* hipMalloc failed */
+#define SWR_ERR_NO_DEVICE     (-4)  /* no gfx950 device / runtime missing */
+#define SWR_ERR_UNSUPPORTED   (-5)
+
+/* Rasterizer.DebugMode, Rasterizer.cs:14-18 */
+enum { SWR_DEBUG_NONE = 0, SWR_DEBUG_WIREFRAME = 1 };
+/* Rasterizer.BlendMode, Rasterizer.cs:25-31 */
+enum { SWR_BLEND_NONE = 0, SWR_BLEND_ALPHA = 1, SWR_BLEND_ADDITIVE = 2, SWR_BLEND_MULTIPLY = 3 };
+/* Rasterizer.DepthTest, Rasterizer.cs:33-43 */
+enum { SWR_DEPTH_DISABLED = 0, SWR_DEPTH_LESS = 1, SWR_DEPTH_LESSEQUAL = 2, SWR_DEPTH_GREATER = 3,
+       SWR_DEPTH_GREATEREQUAL = 4, SWR_DEPTH_EQUAL = 5, SWR_DEPTH_NOTEQUAL = 6, SWR_DEPTH_ALWAYS = 7 };
+/* Rasterizer.CullMode, Rasterizer.cs:45-50 */
+enum { SWR_CULL_NONE = 0, SWR_CULL_BACK = 1, SWR_CULL_FRONT = 2 };
+
+/* Built-in shader programs: C# delegates (Shaders.cs:97-98) cannot cross the ABI, so a
+ * program id selects a (vertex, fragment) pair compiled into the backend. */
+enum {
+    SWR_PROG_FLAT_COLOR = 0,        /* VS of Renderer.cs:830-846 with Interpolate=false; FS = input.Color */
+    SWR_PROG_GOURAUD = 1,           /* same VS, Interpolate=true; FS = input.Color */
+    SWR_PROG_DUST2_LAMBERT_FOG = 2, /* exactly Renderer.VertexShader/FragmentShader, Renderer.cs:830-860 */
+    SWR_PROG_PHONG_4POINT = 3       /* build-defined 4-point-light Phong (no reference semantics) */
+};
+
+/* Shaders.VertexInput, Shaders.cs:10-24 -- 48 bytes, identical memory layout */
+typedef struct swr_vertex {
+    float position[3];
+    float uv[2];
+    float normal[3];
+    float color[4];
+} swr_vertex;
+
+typedef struct swr_point_light {      /* subset of Light.cs:9-17 used by PHONG_4POINT */
+    float position[3]; float range;
+    float color[3];    float intensity;
+} swr_point_light;
+
+/* Uniform block: the fields Renderer.FragmentShader closes over, Renderer.cs:39-44 */
+typedef struct swr_uniforms {
+    float light_direction[3]; float _pad0;
+    float light_color[4];
+    float fog_color[4];
+    float fog_start, fog_end;
+    float shininess; float _pad1;
+    float camera_position[3]; float _pad2;
+    swr_point_light lights[4];
+} swr_uniforms;
+
+typedef struct swr_stats {            /* counters for the last flushed batch and totals since reset */
+    uint64_t triangles_in;            /* index triples submitted to RenderMesh */
+    uint64_t triangles_setup;         /* triangles that reached the tile loop (after clip/cull/reject) */
+    uint64_t triangles_clipped;       /* went through the near-plane clipper */
+    uint64_t fragments_tested;        /* passed coverage (Rasterizer.cs:493-496) */
+    uint64_t fragments_shaded;        /* passed the depth test */
+    uint64_t fragments_written;       /* passed alpha, pixel written (Rasterizer.cs:511-519) */
+    uint64_t tile_pairs;              /* (triangle, 16x16 tile) pairs binned */
+    uint64_t flushes;
+} swr_stats;
+
+/* per-stage GPU time of flushes since swr_profile_reset, from hipEvents on the context's stream */
+typedef struct swr_profile {
+    double vertex_ms, setup_ms, bin_ms, sort_ms, raster_ms, clear_ms, total_ms;
+    uint64_t raster_launches, flushes;
+} swr_profile;
+
+typedef struct swr_context swr_context;
+typedef struct swr_mesh swr_mesh;
+typedef struct swr_texture swr_texture;
+
+int  swr_abi_version(void);
+const char* swr_last_error(const swr_context* ctx);   /* ctx may be NULL: last swr_create failure */
+
+/* lifetime -------------------------------------------------------------------------------- */
+int  swr_create(int device_id, swr_context** out);
+void swr_destroy(swr_context* ctx);
+
+/* framebuffer == MainWindow.ColorBuffer / DepthBuffer (MainWindow.cs:25-31) ------------------ */
+/* allocates Vector4[W*H] + float[W*H] in HBM; ≙ MainWindow.HandleResize (MainWindow.cs:320-321).
+ * W or H <= 0 gives a zero-size target on which every draw is silently skipped (Rasterizer.cs:176). */
+int  swr_resize(swr_context* ctx, int width, int height);
+/* multi-GPU: this context renders only tile rows [first_tile_row, first_tile_row + n_tile_rows) of the
+ * W x H frame; its buffers hold just those rows.  Default = whole frame. */
+int  swr_set_band(swr_context* ctx, int first_tile_row, int n_tile_rows);
+/* use caller-provided device memory (e.g. a torch tensor that RCCL will gather) for the band's
+ * colour (float4 per pixel) and depth (float per pixel); NULL returns to internal storage */
+int  swr_bind_framebuffer(swr_context* ctx, void* color_device_ptr, void* depth_device_ptr);
+int  swr_set_stream(swr_context* ctx, void* hip_stream);      /* hipStream_t; NULL = context's own stream */
+int  swr_clear_color(swr_context* ctx, const float rgba[4]);   /* MainWindow.ClearColorBuffer, MainWindow.cs:400-407 */
+int  swr_clear_depth(swr_context* ctx);                        /* MainWindow.ClearDepthBuffer -> float.MinValue, :429-436 */
+int  swr_get_pixel(swr_context* ctx, int x, int y, float rgba[4]);       /* MainWindow.GetPixel :391-398 (OOB -> 0) */
+int  swr_set_pixel(swr_context* ctx, int x, int y, const float rgba[4]); /* MainWindow.SetPixel :382-388 (OOB ignored) */
+int  swr_get_depth(swr_context* ctx, int x, int y, float* depth);        /* MainWindow.GetDepth :420-426 (OOB -> MinValue) */
+int  swr_set_depth(swr_context* ctx, int x, int y, float depth);         /* MainWindow.SetDepth :411-417 */
+/* flush, then copy the band into caller memory (either pointer may be NULL); ≙ the host reading
+ * ColorBuffer/DepthBuffer in MainWindow.OnRender (MainWindow.cs:226-263) */
+int  swr_readback(swr_context* ctx, float* color_rgba, float* depth);
+/* upload caller memory into the band (tests: resume from a known framebuffer state) */
+int  swr_upload(swr_context* ctx, const float* color_rgba, const float* depth);
+int  swr_color_device_ptr(swr_context* ctx, void** out);
+int  swr_depth_device_ptr(swr_context* ctx, void** out);
+
+/* retained resources -------------------------------------------------------------------------- */
+/* Texture(Image<Rgba32>) ctor / Dispose, Texture.cs:31-41,65-68: RGBA8 row-major, w*h*4 bytes */
+int  swr_texture_create(swr_context* ctx, const uint8_t* rgba8, int width, int height, swr_texture** out);
+int  swr_texture_destroy(swr_context* ctx, swr_texture* tex);
+/* Texture.Sample, Texture.cs:43-63, batched: n uv pairs -> n RGBA float4 (runs on the GPU) */
+int  swr_texture_sample(swr_context* ctx, const swr_texture* tex, const float* uv, int n, float* out_rgba);
+/* mesh.Vertices / mesh.Indices (ModelLoader.cs:45-47): u16 indices, 3 per triangle; an index >= n_vertices
+ * is SWR_ERR_INVALID_ARG (C#: IndexOutOfRangeException at Rasterizer.cs:187) */
+int  swr_mesh_create(swr_context* ctx, const swr_vertex* vertices, int n_vertices,
+                     const uint16_t* indices, int n_indices, swr_mesh** out);
+int  swr_mesh_destroy(swr_context* ctx, swr_mesh* mesh);
+
+/* state ≙ public statics Rasterizer.NearClip / FarClip / RenderDebugMode, Rasterizer.cs:20-22 */
+int  swr_set_state(swr_context* ctx, float near_clip, float far_clip, int debug_mode);
+/* Rasterizer.InitializeTileLocks, Rasterizer.cs:69-93: width/height <= 0 -> SWR_ERR_INVALID_ARG */
+int  swr_initialize_tile_locks(swr_context* ctx, int width, int height);
+
+/* draw ≙ Rasterizer.RenderMesh, Rasterizer.cs:163-174 --------------------------------------- */
+int  swr_render_mesh(swr_context* ctx, const swr_mesh* mesh,
+                     const float model[16], const float view[16], const float projection[16],
+                     int program, const swr_uniforms* uniforms, const swr_texture* texture /* NULL -> white */,
+                     int cull_mode, int depth_test, int blend_mode);
+/* same, taking the arrays of the C# signature directly (copied to HBM for this draw only) */
+int  swr_render_mesh_arrays(swr_context* ctx, const swr_vertex* vertices, int n_vertices,
+                            const uint16_t* indices, int n_indices,
+                            const float model[16], const float view[16], const float projection[16],
+                            int program, const swr_uniforms* uniforms, const swr_texture* texture,
+                            int cull_mode, int depth_test, int blend_mode);
+int  swr_flush(swr_context* ctx);    /* execute recorded draws (asynchronous on the stream) */
+int  swr_sync(swr_context* ctx);     /* flush + wait for the stream */
+
+/* Rasterizer.Interpolate (public, Rasterizer.cs:566-640), batched on the GPU for API coverage:
+ * verts = 3 vertex records of 20 floats {clip4,color4,uv2,normal3,screen2,worldNormal3,pad2};
+ * w = n * 3 barycentric weights; out = n records of 24 floats
+ * {clip4,color4,uv2,normal3,screen2,worldNormal3,bary3,pad3} */
+int  swr_interpolate(swr_context* ctx, const float* verts60, const float* w, int n, int interpolate, float* out);
+
+/* counters / profiling ------------------------------------------------------------------------ */
+int  swr_get_stats(swr_context* ctx, swr_stats* out);   /* syncs */
+int  swr_reset_stats(swr_context* ctx);
+int  swr_profile_enable(swr_context* ctx, int on);       /* hipEvent pairs around every kernel of a flush */
+int  swr_profile_get(swr_context* ctx, swr_profile* out); /* syncs */
+int  swr_profile_reset(swr_context* ctx);
+int  swr_device_name(swr_context* ctx, char* buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWR_H */

@@ -1,0 +1,805 @@
+// swr_api.hip -- host side of libswr_hip.so: the C ABI of include/swr.h over the gfx950 kernels.
+//
+// A context records draws (Rasterizer.RenderMesh calls, Rasterizer.cs:163-174) in submission order
+// and executes them as ONE batch per flush:
+//     k_vertex -> k_setup -> k_bin<count> -> k_scan -> k_bin<fill> -> k_sort_tiles -> k_raster
+// There is no CPU fallback anywhere in this file: every pixel is produced by the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "swr.h"
+#include "swr_device.h"
+#include "swr_geometry.hip.h"
+#include "swr_binning.hip.h"
+#include "swr_raster.hip.h"
+
+using namespace swr;
+
+struct swr_mesh {
+    swr_vertex* d_verts = nullptr;
+    uint16_t* d_idx = nullptr;
+    int n_verts = 0, n_idx = 0;
+    bool transient = false;
+};
+struct swr_texture {
+    uint8_t* d_rgba = nullptr;
+    int w = 0, h = 0;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Stage { ST_VERTEX = 0, ST_SETUP, ST_BIN, ST_SORT, ST_RASTER, ST_CLEAR, ST_COUNT };
+
+struct EventSpan { int stage; hipEvent_t a, b; };
+
+struct DrawCmd {
+    DrawParams p;
+    swr_mesh* mesh;
+};
+
+}  // namespace
+
+struct swr_context {
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    char dev_name[256] = { 0 };
+
+    int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
+    bool band_set = false;
+    int band_first = 0, band_count = 0;       // as requested by swr_set_band
+    int band_ty0 = 0, band_ty1 = 0;           // effective
+    float4* color = nullptr;                  // band storage in use (own or external)
+    float* depth = nullptr;
+    DevBuf own_color, own_depth;
+    void* ext_color = nullptr; void* ext_depth = nullptr;
+
+    float near_clip = 0.1f, far_clip = 1000.0f;   // Rasterizer.cs:20-21
+    int debug_mode = SWR_DEBUG_NONE;               // Rasterizer.cs:22
+
+    bool pend_clear_color = false, pend_clear_depth = false;
+    float clear_rgba[4] = { 0, 0, 0, 0 };
+
+    std::vector<DrawCmd> draws;
+    uint64_t pend_verts = 0, pend_tris = 0;
+    std::vector<swr_mesh*> garbage;           // transient meshes to free at the next sync point
+
+    DevBuf d_draws, d_vblocks, d_tblocks, d_vout, d_recs, d_slot_tb;
+    DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
+    size_t tile_stats_tiles = 0;
+    swr_stats totals = {};
+
+    bool profiling = false;
+    std::vector<EventSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    swr_profile prof = {};
+};
+
+namespace {
+
+#define SWR_HIP(ctx, call)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            char b_[512];                                                                         \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = b_;                                                                      \
+            return e_ == hipErrorOutOfMemory ? SWR_ERR_OOM : SWR_ERR_HIP;                         \
+        }                                                                                         \
+    } while (0)
+
+int fail(swr_context* c, int code, const char* msg) { c->err = msg; return code; }
+
+int ensure(swr_context* c, DevBuf& b, size_t bytes, bool zero_new = false) {
+    if (bytes <= b.cap) return SWR_OK;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    if (b.p) { SWR_HIP(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    SWR_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    if (zero_new) SWR_HIP(c, hipMemsetAsync(b.p, 0, want, c->stream));
+    return SWR_OK;
+}
+
+void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+int band_y0(const swr_context* c) { return c->band_ty0 * SWR_TILE; }
+int band_rows(const swr_context* c) {
+    int y1 = std::min(c->H, c->band_ty1 * SWR_TILE);
+    return std::max(0, y1 - band_y0(c));
+}
+size_t band_pixels(const swr_context* c) { return (size_t)std::max(0, c->W) * (size_t)band_rows(c); }
+
+int apply_geometry(swr_context* c) {
+    c->tiles_x = c->W > 0 ? (c->W + SWR_TILE - 1) / SWR_TILE : 0;     // Rasterizer.cs:76-77
+    c->tiles_y = c->H > 0 ? (c->H + SWR_TILE - 1) / SWR_TILE : 0;
+    if (c->band_set) {
+        c->band_ty0 = std::min(std::max(c->band_first, 0), c->tiles_y);
+        c->band_ty1 = std::min(c->band_ty0 + std::max(c->band_count, 0), c->tiles_y);
+    } else {
+        c->band_ty0 = 0; c->band_ty1 = c->tiles_y;
+    }
+    size_t n = band_pixels(c);
+    if (c->ext_color) {
+        c->color = (float4*)c->ext_color; c->depth = (float*)c->ext_depth;
+    } else {
+        int rc;
+        if ((rc = ensure(c, c->own_color, std::max<size_t>(n, 1) * sizeof(float4), false))) return rc;
+        if ((rc = ensure(c, c->own_depth, std::max<size_t>(n, 1) * sizeof(float), false))) return rc;
+        c->color = c->own_color.as<float4>(); c->depth = c->own_depth.as<float>();
+    }
+    return SWR_OK;
+}
+
+FrameParams frame_params(const swr_context* c) {
+    FrameParams fp;
+    fp.width = c->W; fp.height = c->H; fp.tiles_x = c->tiles_x; fp.tiles_y = c->tiles_y;
+    fp.band_ty0 = c->band_ty0; fp.band_ty1 = c->band_ty1;
+    fp.band_y0 = band_y0(c); fp.band_rows = band_rows(c);
+    fp.near_clip = c->near_clip;
+    return fp;
+}
+
+hipEvent_t get_event(swr_context* c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ScopedSpan {
+    swr_context* c; int stage; hipEvent_t a = nullptr, b = nullptr;
+    ScopedSpan(swr_context* c_, int st) : c(c_), stage(st) {
+        if (c->profiling) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~ScopedSpan() {
+        if (c->profiling) { (void)hipEventRecord(b, c->stream); c->spans.push_back({ stage, a, b }); }
+    }
+};
+
+void collect_spans(swr_context* c) {      // stream must be idle
+    for (auto& s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            switch (s.stage) {
+            case ST_VERTEX: c->prof.vertex_ms += ms; break;
+            case ST_SETUP:  c->prof.setup_ms += ms; break;
+            case ST_BIN:    c->prof.bin_ms += ms; break;
+            case ST_SORT:   c->prof.sort_ms += ms; break;
+            case ST_RASTER: c->prof.raster_ms += ms; c->prof.raster_launches++; break;
+            case ST_CLEAR:  c->prof.clear_ms += ms; break;
+            }
+            c->prof.total_ms += ms;
+        }
+        c->event_pool.push_back(s.a); c->event_pool.push_back(s.b);
+    }
+    c->spans.clear();
+}
+
+void free_garbage(swr_context* c) {       // stream must be idle
+    for (swr_mesh* m : c->garbage) {
+        if (m->d_verts) (void)hipFree(m->d_verts);
+        if (m->d_idx) (void)hipFree(m->d_idx);
+        delete m;
+    }
+    c->garbage.clear();
+}
+
+int sync_locked(swr_context* c) {
+    SWR_HIP(c, hipStreamSynchronize(c->stream));
+    collect_spans(c);
+    free_garbage(c);
+    return SWR_OK;
+}
+
+int run_clear(swr_context* c) {
+    size_t n = band_pixels(c);
+    if (n && (c->pend_clear_color || c->pend_clear_depth)) {
+        ScopedSpan sp(c, ST_CLEAR);
+        int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
+        float4 rgba = make_float4(c->clear_rgba[0], c->clear_rgba[1], c->clear_rgba[2], c->clear_rgba[3]);
+        hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, c->stream, c->color, c->depth, n, rgba,
+                           c->pend_clear_color ? 1 : 0, c->pend_clear_depth ? 1 : 0);
+        SWR_HIP(c, hipGetLastError());
+    }
+    c->pend_clear_color = c->pend_clear_depth = false;
+    return SWR_OK;
+}
+
+// bins slots [lo, hi) and rasterises them; splits the range when the pair list would not fit
+int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi) {
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+    if (n_tiles == 0 || lo >= hi) return SWR_OK;
+    int rc;
+    BinArgs ba;
+    ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
+    ba.slot_lo = lo; ba.slot_hi = hi;
+    ba.tiles_x = c->tiles_x; ba.band_ty0 = c->band_ty0; ba.band_ty1 = c->band_ty1;
+    ba.tile_count = c->d_tile_count.as<uint32_t>();
+    ba.tile_start = c->d_tile_start.as<uint32_t>();
+    ba.tile_list = c->d_tile_list.as<uint32_t>();
+    ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
+    ba.counters = c->d_counters.as<Counters>();
+    const uint32_t bin_blocks = (hi - lo + 255u) / 256u;
+    unsigned long long total = 0;
+    {
+        ScopedSpan sp(c, ST_BIN);
+        SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
+        hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, ba.tile_count, c->d_tile_start.as<uint32_t>(),
+                           n_tiles, c->d_total.as<unsigned long long>());
+        SWR_HIP(c, hipGetLastError());
+    }
+    SWR_HIP(c, hipMemcpyAsync(&total, c->d_total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    SWR_HIP(c, hipStreamSynchronize(c->stream));
+
+    const unsigned long long max_pairs = 1ull << 30;       // 4 GiB of list entries per round
+    if (total > max_pairs && hi - lo > 2) {
+        // too many (triangle, tile) pairs for one round: split the slot range.  Order is preserved
+        // because the framebuffer carries the state from one round to the next.
+        uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
+        if (mid == lo) mid = lo + 2;
+        if ((rc = bin_and_raster(c, lo, mid))) return rc;
+        return bin_and_raster(c, mid, hi);
+    }
+    c->totals.tile_pairs += total;
+    if (total == 0) return run_clear(c);
+    if (total > 0xffffffffull) return fail(c, SWR_ERR_UNSUPPORTED, "a single triangle covers more tile pairs than one round can hold");
+
+    if ((rc = ensure(c, c->d_tile_list, (size_t)total * 4))) return rc;
+    ba.tile_list = c->d_tile_list.as<uint32_t>();
+    ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
+    {
+        ScopedSpan sp(c, ST_BIN);
+        SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
+        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
+        SWR_HIP(c, hipGetLastError());
+    }
+    {
+        ScopedSpan sp(c, ST_SORT);
+        hipLaunchKernelGGL(k_sort_tiles, dim3(n_tiles), dim3(64), 0, c->stream, c->d_tile_start.as<uint32_t>(),
+                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles);
+        SWR_HIP(c, hipGetLastError());
+    }
+    {
+        ScopedSpan sp(c, ST_RASTER);
+        RasterArgs ra;
+        ra.fp = frame_params(c);
+        ra.recs = c->d_recs.as<TriRec>();
+        ra.vout = c->d_vout.as<VOut>();
+        ra.draws = c->d_draws.as<DrawParams>();
+        ra.tile_start = c->d_tile_start.as<uint32_t>();
+        ra.tile_count = c->d_tile_count.as<uint32_t>();
+        ra.tile_list = c->d_tile_list.as<uint32_t>();
+        ra.color = c->color; ra.depth = c->depth;
+        ra.tile_stats = c->d_tile_stats.as<uint32_t>();
+        memcpy(ra.clear_rgba, c->clear_rgba, 16);
+        ra.clear_color_on = c->pend_clear_color ? 1 : 0;
+        ra.clear_depth_on = c->pend_clear_depth ? 1 : 0;
+        ra.blocks_x = (c->tiles_x + 1) / 2;
+        ra.blocks_y = (c->band_ty1 - c->band_ty0 + 1) / 2;
+        hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        SWR_HIP(c, hipGetLastError());
+        c->pend_clear_color = c->pend_clear_depth = false;
+    }
+    return SWR_OK;
+}
+
+int flush_locked(swr_context* c) {
+    if (c->W <= 0 || c->H <= 0 || band_pixels(c) == 0) {          // Rasterizer.cs:176: silently skip
+        for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+        c->draws.clear(); c->pend_verts = c->pend_tris = 0;
+        c->pend_clear_color = c->pend_clear_depth = false;
+        return SWR_OK;
+    }
+    if (c->draws.empty()) return run_clear(c);
+
+    int rc;
+    const size_t nd = c->draws.size();
+    std::vector<DrawParams> hp(nd);
+    std::vector<BlockMap> vblocks, tblocks;
+    uint64_t V = 0, T = 0;
+    for (size_t i = 0; i < nd; ++i) {
+        DrawParams p = c->draws[i].p;
+        p.vert_base = (uint32_t)V; p.tri_base = (uint32_t)T;
+        for (uint32_t f = 0; f < p.n_verts; f += 256) vblocks.push_back({ (uint32_t)i, f });
+        for (uint32_t f = 0; f < p.n_tris; f += 256) tblocks.push_back({ (uint32_t)i, f });
+        V += p.n_verts; T += p.n_tris;
+        hp[i] = p;
+    }
+    if (V + 4 * T >= 0xffffffffull || 2 * T >= 0xffffffffull)
+        return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
+    if (T == 0) {
+        for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+        c->draws.clear(); c->pend_verts = c->pend_tris = 0;
+        return run_clear(c);
+    }
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+
+    if ((rc = ensure(c, c->d_draws, nd * sizeof(DrawParams)))) return rc;
+    if ((rc = ensure(c, c->d_vblocks, std::max<size_t>(vblocks.size(), 1) * sizeof(BlockMap)))) return rc;
+    if ((rc = ensure(c, c->d_tblocks, tblocks.size() * sizeof(BlockMap)))) return rc;
+    if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
+    if ((rc = ensure(c, c->d_recs, (size_t)(2 * T) * sizeof(TriRec)))) return rc;
+    if ((rc = ensure(c, c->d_slot_tb, (size_t)(2 * T) * 8))) return rc;
+    if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
+    if (c->tile_stats_tiles != n_tiles) {
+        if ((rc = ensure(c, c->d_tile_stats, (size_t)n_tiles * 12))) return rc;
+        SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
+        c->tile_stats_tiles = n_tiles;
+    }
+
+    SWR_HIP(c, hipMemcpyAsync(c->d_draws.p, hp.data(), nd * sizeof(DrawParams), hipMemcpyHostToDevice, c->stream));
+    if (!vblocks.empty())
+        SWR_HIP(c, hipMemcpyAsync(c->d_vblocks.p, vblocks.data(), vblocks.size() * sizeof(BlockMap), hipMemcpyHostToDevice, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(c->d_tblocks.p, tblocks.data(), tblocks.size() * sizeof(BlockMap), hipMemcpyHostToDevice, c->stream));
+    // pageable sources: the copies above are staged before returning, so the vectors may die at scope end
+
+    const FrameParams fp = frame_params(c);
+    if (!vblocks.empty()) {
+        ScopedSpan sp(c, ST_VERTEX);
+        hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
+                           c->d_draws.as<DrawParams>(), c->d_vblocks.as<BlockMap>(), c->d_vout.as<VOut>());
+        SWR_HIP(c, hipGetLastError());
+    }
+    {
+        ScopedSpan sp(c, ST_SETUP);
+        hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, c->stream,
+                           c->d_draws.as<DrawParams>(), c->d_tblocks.as<BlockMap>(), c->d_vout.as<VOut>(),
+                           c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
+                           c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>());
+        SWR_HIP(c, hipGetLastError());
+    }
+    rc = bin_and_raster(c, 0, (uint32_t)(2 * T));
+    for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+    c->draws.clear(); c->pend_verts = c->pend_tris = 0;
+    c->totals.flushes++;
+    if (rc) return rc;
+    if (c->pend_clear_color || c->pend_clear_depth) return run_clear(c);   // nothing was binned
+    return SWR_OK;
+}
+
+int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
+                int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
+    if (!mesh || !model || !view || !proj) return fail(c, SWR_ERR_INVALID_ARG, "null argument to render_mesh");
+    if (program < SWR_PROG_FLAT_COLOR || program > SWR_PROG_PHONG_4POINT)
+        return fail(c, SWR_ERR_INVALID_ARG, "unknown program id");
+    if ((program == SWR_PROG_DUST2_LAMBERT_FOG || program == SWR_PROG_PHONG_4POINT) && !u)
+        return fail(c, SWR_ERR_INVALID_ARG, "this program needs a uniform block");
+    if (cull < 0 || cull > 2 || depth_test < 0 || depth_test > 7 || blend < 0 || blend > 3)
+        return fail(c, SWR_ERR_INVALID_ARG, "enum value out of range");
+    if (c->debug_mode == SWR_DEBUG_WIREFRAME)
+        return fail(c, SWR_ERR_UNSUPPORTED, "DebugMode.Wireframe (Rasterizer.DrawLine) is not implemented by the HIP backend yet");
+    if (c->W <= 0 || c->H <= 0) return SWR_OK;                      // Rasterizer.cs:176
+    const int n_tris = mesh->n_idx / 3;                             // Rasterizer.cs:180
+    if (n_tris == 0) return SWR_OK;
+    // keep a batch within the 32-bit slot / vertex numbering
+    if (c->pend_tris + (uint64_t)n_tris > (1ull << 28) || c->pend_verts + (uint64_t)mesh->n_verts > (1ull << 28)) {
+        int rc = flush_locked(c);
+        if (rc) return rc;
+    }
+    DrawCmd d;
+    memset(&d.p, 0, sizeof d.p);
+    memcpy(d.p.model, model, 64); memcpy(d.p.view, view, 64); memcpy(d.p.proj, proj, 64);
+    if (u) d.p.u = *u;
+    d.p.verts = mesh->d_verts; d.p.idx = mesh->d_idx;
+    d.p.tex = tex ? tex->d_rgba : nullptr;
+    d.p.tex_w = tex ? tex->w : 0; d.p.tex_h = tex ? tex->h : 0;
+    d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
+    d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
+    d.mesh = mesh;
+    c->draws.push_back(d);
+    c->pend_verts += mesh->n_verts; c->pend_tris += n_tris;
+    return SWR_OK;
+}
+
+int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, int ni, bool transient, swr_mesh** out) {
+    if (nv < 0 || ni < 0 || (nv > 0 && !v) || (ni > 0 && !idx) || !out) return fail(c, SWR_ERR_INVALID_ARG, "bad mesh arguments");
+    const int used = (ni / 3) * 3;
+    for (int i = 0; i < used; ++i)
+        if ((int)idx[i] >= nv) return fail(c, SWR_ERR_INVALID_ARG, "index out of range (C#: IndexOutOfRangeException)");
+    swr_mesh* m = new swr_mesh();
+    m->n_verts = nv; m->n_idx = ni; m->transient = transient;
+    hipError_t e = hipSuccess;
+    if (nv) e = hipMalloc((void**)&m->d_verts, (size_t)nv * sizeof(swr_vertex));
+    if (e == hipSuccess && ni) e = hipMalloc((void**)&m->d_idx, (size_t)ni * 2 + 8);
+    if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        if (m->d_verts) (void)hipFree(m->d_verts);
+        if (m->d_idx) (void)hipFree(m->d_idx);
+        delete m;
+        c->err = std::string("mesh upload failed: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? SWR_ERR_OOM : SWR_ERR_HIP;
+    }
+    *out = m;
+    return SWR_OK;
+}
+
+bool in_band(const swr_context* c, int x, int y) {
+    return x >= 0 && x < c->W && y >= band_y0(c) && y < band_y0(c) + band_rows(c);
+}
+
+}  // namespace
+
+extern "C" {
+
+int swr_abi_version(void) { return SWR_ABI_VERSION; }
+
+const char* swr_last_error(const swr_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int swr_create(int device_id, swr_context** out) {
+    if (!out) { g_create_error = "out is null"; return SWR_ERR_INVALID_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e) + " (this backend has no CPU fallback)";
+        return SWR_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return SWR_ERR_INVALID_ARG; }
+    if ((e = hipSetDevice(device_id)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SWR_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SWR_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + "; libswr_hip.so carries gfx950 code objects only";
+        return SWR_ERR_NO_DEVICE;
+    }
+    swr_context* c = new swr_context();
+    c->device = device_id;
+    snprintf(c->dev_name, sizeof c->dev_name, "%s (%s)", prop.name, prop.gcnArchName);
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
+        g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
+    if (!rc) rc = ensure(c, c->d_total, 64);
+    if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
+    if (rc) { g_create_error = c->err; swr_destroy(c); return rc; }
+    *out = c;
+    return SWR_OK;
+}
+
+void swr_destroy(swr_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+    collect_spans(c);
+    free_garbage(c);
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_draws, &c->d_vblocks, &c->d_tblocks, &c->d_vout, &c->d_recs,
+                       &c->d_slot_tb, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
+                       &c->d_counters, &c->d_total, &c->d_scratch };
+    for (DevBuf* b : bufs) release(*b);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+#define SWR_ENTER(c)                                   \
+    if (!(c)) return SWR_ERR_INVALID_ARG;              \
+    std::lock_guard<std::mutex> lock_((c)->mu);        \
+    (void)hipSetDevice((c)->device)
+
+int swr_resize(swr_context* c, int width, int height) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if (width > 65535 || height > 65535) return fail(c, SWR_ERR_INVALID_ARG, "render target larger than 65535");
+    c->W = width; c->H = height;
+    c->tile_stats_tiles = 0;
+    return apply_geometry(c);
+}
+
+int swr_set_band(swr_context* c, int first_tile_row, int n_tile_rows) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if (first_tile_row < 0 || n_tile_rows < 0) { c->band_set = false; }
+    else { c->band_set = true; c->band_first = first_tile_row; c->band_count = n_tile_rows; }
+    c->tile_stats_tiles = 0;
+    return apply_geometry(c);
+}
+
+int swr_bind_framebuffer(swr_context* c, void* color, void* depth) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if ((color == nullptr) != (depth == nullptr)) return fail(c, SWR_ERR_INVALID_ARG, "bind both colour and depth, or neither");
+    c->ext_color = color; c->ext_depth = depth;
+    return apply_geometry(c);
+}
+
+int swr_set_stream(swr_context* c, void* s) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return SWR_OK;
+}
+
+int swr_clear_color(swr_context* c, const float rgba[4]) {
+    SWR_ENTER(c);
+    if (!rgba) return fail(c, SWR_ERR_INVALID_ARG, "rgba is null");
+    if (!c->draws.empty()) { int rc = flush_locked(c); if (rc) return rc; }
+    memcpy(c->clear_rgba, rgba, 16);
+    c->pend_clear_color = true;
+    return SWR_OK;
+}
+
+int swr_clear_depth(swr_context* c) {
+    SWR_ENTER(c);
+    if (!c->draws.empty()) { int rc = flush_locked(c); if (rc) return rc; }
+    c->pend_clear_depth = true;
+    return SWR_OK;
+}
+
+int swr_flush(swr_context* c) { SWR_ENTER(c); return flush_locked(c); }
+
+int swr_sync(swr_context* c) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    return sync_locked(c);
+}
+
+int swr_readback(swr_context* c, float* color, float* depth) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    size_t n = band_pixels(c);
+    if (n) {
+        if (color) SWR_HIP(c, hipMemcpyAsync(color, c->color, n * 16, hipMemcpyDeviceToHost, c->stream));
+        if (depth) SWR_HIP(c, hipMemcpyAsync(depth, c->depth, n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    return sync_locked(c);
+}
+
+int swr_upload(swr_context* c, const float* color, const float* depth) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    size_t n = band_pixels(c);
+    if (n) {
+        if (color) SWR_HIP(c, hipMemcpyAsync(c->color, color, n * 16, hipMemcpyHostToDevice, c->stream));
+        if (depth) SWR_HIP(c, hipMemcpyAsync(c->depth, depth, n * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    return sync_locked(c);
+}
+
+int swr_color_device_ptr(swr_context* c, void** out) { SWR_ENTER(c); if (!out) return SWR_ERR_INVALID_ARG; *out = c->color; return SWR_OK; }
+int swr_depth_device_ptr(swr_context* c, void** out) { SWR_ENTER(c); if (!out) return SWR_ERR_INVALID_ARG; *out = c->depth; return SWR_OK; }
+
+int swr_get_pixel(swr_context* c, int x, int y, float rgba[4]) {
+    SWR_ENTER(c);
+    if (!rgba) return SWR_ERR_INVALID_ARG;
+    rgba[0] = rgba[1] = rgba[2] = rgba[3] = 0.0f;                 // Vector4.Zero out of bounds, MainWindow.cs:397
+    if (!in_band(c, x, y)) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(rgba, c->color + (size_t)(y - band_y0(c)) * c->W + x, 16, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
+}
+int swr_set_pixel(swr_context* c, int x, int y, const float rgba[4]) {
+    SWR_ENTER(c);
+    if (!rgba) return SWR_ERR_INVALID_ARG;
+    if (!in_band(c, x, y)) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(c->color + (size_t)(y - band_y0(c)) * c->W + x, rgba, 16, hipMemcpyHostToDevice, c->stream));
+    return sync_locked(c);
+}
+int swr_get_depth(swr_context* c, int x, int y, float* d) {
+    SWR_ENTER(c);
+    if (!d) return SWR_ERR_INVALID_ARG;
+    *d = SWR_FLOAT_MINVALUE;                                       // MainWindow.cs:425
+    if (!in_band(c, x, y)) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(d, c->depth + (size_t)(y - band_y0(c)) * c->W + x, 4, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
+}
+int swr_set_depth(swr_context* c, int x, int y, float d) {
+    SWR_ENTER(c);
+    if (!in_band(c, x, y)) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(c->depth + (size_t)(y - band_y0(c)) * c->W + x, &d, 4, hipMemcpyHostToDevice, c->stream));
+    return sync_locked(c);
+}
+
+int swr_texture_create(swr_context* c, const uint8_t* rgba8, int w, int h, swr_texture** out) {
+    SWR_ENTER(c);
+    if (!rgba8 || w <= 0 || h <= 0 || !out) return fail(c, SWR_ERR_INVALID_ARG, "bad texture arguments");
+    swr_texture* t = new swr_texture();
+    t->w = w; t->h = h;
+    hipError_t e = hipMalloc((void**)&t->d_rgba, (size_t)w * h * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(t->d_rgba, rgba8, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) {
+        if (t->d_rgba) (void)hipFree(t->d_rgba);
+        delete t;
+        c->err = std::string("texture upload failed: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? SWR_ERR_OOM : SWR_ERR_HIP;
+    }
+    *out = t;
+    return SWR_OK;
+}
+
+int swr_texture_destroy(swr_context* c, swr_texture* t) {
+    SWR_ENTER(c);
+    if (!t) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if (t->d_rgba) (void)hipFree(t->d_rgba);
+    delete t;
+    return SWR_OK;
+}
+
+int swr_texture_sample(swr_context* c, const swr_texture* t, const float* uv, int n, float* out) {
+    SWR_ENTER(c);
+    if (!t || !uv || !out || n < 0) return fail(c, SWR_ERR_INVALID_ARG, "bad texture_sample arguments");
+    if (n == 0) return SWR_OK;
+    const size_t off_out = ((size_t)n * 8 + 15) & ~(size_t)15;
+    int rc = ensure(c, c->d_scratch, off_out + (size_t)n * 16);
+    if (rc) return rc;
+    float2* d_uv = c->d_scratch.as<float2>();
+    float4* d_out = reinterpret_cast<float4*>(reinterpret_cast<char*>(c->d_scratch.p) + off_out);
+    SWR_HIP(c, hipMemcpyAsync(d_uv, uv, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_texture_sample, dim3((n + 255) / 256), dim3(256), 0, c->stream, t->d_rgba, t->w, t->h, d_uv, n, d_out);
+    SWR_HIP(c, hipGetLastError());
+    SWR_HIP(c, hipMemcpyAsync(out, d_out, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
+}
+
+int swr_mesh_create(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, int ni, swr_mesh** out) {
+    SWR_ENTER(c);
+    return make_mesh(c, v, nv, idx, ni, false, out);
+}
+
+int swr_mesh_destroy(swr_context* c, swr_mesh* m) {
+    SWR_ENTER(c);
+    if (!m) return SWR_OK;
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if (m->d_verts) (void)hipFree(m->d_verts);
+    if (m->d_idx) (void)hipFree(m->d_idx);
+    delete m;
+    return SWR_OK;
+}
+
+int swr_set_state(swr_context* c, float near_clip, float far_clip, int debug_mode) {
+    SWR_ENTER(c);
+    if (debug_mode != SWR_DEBUG_NONE && debug_mode != SWR_DEBUG_WIREFRAME) return fail(c, SWR_ERR_INVALID_ARG, "bad debug mode");
+    if (!c->draws.empty() && (near_clip != c->near_clip || debug_mode != c->debug_mode)) {
+        int rc = flush_locked(c); if (rc) return rc;     // NearClip is read at clip time (Rasterizer.cs:112)
+    }
+    c->near_clip = near_clip; c->far_clip = far_clip; c->debug_mode = debug_mode;
+    return SWR_OK;
+}
+
+int swr_initialize_tile_locks(swr_context* c, int width, int height) {
+    SWR_ENTER(c);
+    if (width <= 0 || height <= 0)                                 // Rasterizer.cs:71-74
+        return fail(c, SWR_ERR_INVALID_ARG, "Width and height must be positive non-zero values.");
+    return SWR_OK;    // tiles need no locks here: one wave owns one tile
+}
+
+int swr_render_mesh(swr_context* c, const swr_mesh* mesh, const float model[16], const float view[16], const float proj[16],
+                    int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
+    SWR_ENTER(c);
+    return record_draw(c, const_cast<swr_mesh*>(mesh), model, view, proj, program, u, tex, cull, depth_test, blend);
+}
+
+int swr_render_mesh_arrays(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, int ni,
+                           const float model[16], const float view[16], const float proj[16],
+                           int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
+    SWR_ENTER(c);
+    if (c->W <= 0 || c->H <= 0) return SWR_OK;                     // Rasterizer.cs:176
+    swr_mesh* m = nullptr;
+    int rc = make_mesh(c, v, nv, idx, ni, true, &m);
+    if (rc) return rc;
+    const size_t before = c->draws.size();
+    rc = record_draw(c, m, model, view, proj, program, u, tex, cull, depth_test, blend);
+    if (rc || c->draws.size() == before || c->draws.back().mesh != m) c->garbage.push_back(m);   // not referenced by a draw
+    return rc;
+}
+
+int swr_interpolate(swr_context* c, const float* verts60, const float* w, int n, int interpolate, float* out) {
+    SWR_ENTER(c);
+    if (!verts60 || !w || !out || n < 0) return fail(c, SWR_ERR_INVALID_ARG, "bad interpolate arguments");
+    if (n == 0) return SWR_OK;
+    const size_t off_w = 256, off_o = 256 + (((size_t)n * 12 + 15) & ~(size_t)15);
+    int rc = ensure(c, c->d_scratch, off_o + (size_t)n * 96);
+    if (rc) return rc;
+    char* base = reinterpret_cast<char*>(c->d_scratch.p);
+    SWR_HIP(c, hipMemcpyAsync(base, verts60, 240, hipMemcpyHostToDevice, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(base + off_w, w, (size_t)n * 12, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_interpolate, dim3((n + 255) / 256), dim3(256), 0, c->stream,
+                       (const float*)base, (const float*)(base + off_w), n, interpolate, (float*)(base + off_o));
+    SWR_HIP(c, hipGetLastError());
+    SWR_HIP(c, hipMemcpyAsync(out, base + off_o, (size_t)n * 96, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
+}
+
+int swr_get_stats(swr_context* c, swr_stats* out) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    int rc = flush_locked(c); if (rc) return rc;
+    Counters host[65];
+    unsigned long long frag[3] = { 0, 0, 0 };
+    if (c->tile_stats_tiles) {
+        unsigned long long* d3 = c->d_total.as<unsigned long long>() + 1;
+        hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, c->stream, c->d_tile_stats.as<uint32_t>(),
+                           (uint32_t)c->tile_stats_tiles, d3);
+        SWR_HIP(c, hipGetLastError());
+        SWR_HIP(c, hipMemcpyAsync(frag, d3, 24, hipMemcpyDeviceToHost, c->stream));
+    }
+    SWR_HIP(c, hipMemcpyAsync(host, c->d_counters.p, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = sync_locked(c))) return rc;
+    swr_stats s = {};
+    for (int i = 0; i < 65; ++i) {
+        s.triangles_in += host[i].triangles_in; s.triangles_setup += host[i].triangles_setup;
+        s.triangles_clipped += host[i].triangles_clipped;
+    }
+    s.fragments_tested = frag[0]; s.fragments_shaded = frag[1]; s.fragments_written = frag[2];
+    s.tile_pairs = c->totals.tile_pairs;
+    s.flushes = c->totals.flushes;
+    *out = s;
+    return SWR_OK;
+}
+
+int swr_reset_stats(swr_context* c) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream));
+    if (c->tile_stats_tiles) SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, c->tile_stats_tiles * 12, c->stream));
+    c->totals = {};
+    return sync_locked(c);
+}
+
+int swr_profile_enable(swr_context* c, int on) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    c->profiling = on != 0;
+    return SWR_OK;
+}
+int swr_profile_get(swr_context* c, swr_profile* out) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    c->prof.flushes = c->totals.flushes;
+    *out = c->prof;
+    return SWR_OK;
+}
+int swr_profile_reset(swr_context* c) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    c->prof = {};
+    return SWR_OK;
+}
+
+int swr_device_name(swr_context* c, char* buf, int buflen) {
+    SWR_ENTER(c);
+    if (!buf || buflen <= 0) return SWR_ERR_INVALID_ARG;
+    snprintf(buf, (size_t)buflen, "%s", c->dev_name);
+    return SWR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// swr_device.h -- device-side structs and .NET-semantics scalar helpers for the gfx950 backend.
+//
+// Everything here is compiled with -ffp-contract=off: the reference's C# is JIT-compiled
+// without FMA contraction, and depth words must match bit for bit.
+// Division and sqrt are the correctly rounded IEEE forms (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt); f32 denormals are kept (hipcc default).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "swr.h"
+
+#ifndef SWR_NUMERICS_FMA
+#define SWR_NUMERICS_FMA 0   // 1 models a fused MultiplyAddEstimate inside System.Numerics Transform/Lerp
+#endif
+
+#define SWR_TILE 16                      // Rasterizer.cs:53 TileSize -- part of the numerical contract
+#define SWR_FLOAT_MINVALUE (-3.40282347e+38f)   // float.MinValue, MainWindow.cs:425,434
+#define SWR_EPSILON 1e-6f                // Rasterizer.cs:52
+
+namespace swr {
+
+// ---------------------------------------------------------------- device records ----
+// Vertex-stage output kept in HBM: only the varyings a built-in fragment program can read
+// (Shaders.VertexOutput, Shaders.cs:26-47, minus Normal/ScreenCoords/Barycentric which no
+// built-in FS consumes).  64 B = one 16-dword scalar load per vertex in the raster kernel.
+struct VOut {
+    float clip[4];     // ClipPosition
+    float color[4];    // Color
+    float uv[2];       // TexCoord
+    float wn[3];       // Data["WorldNormal"]
+    float wpos[3];     // Data["WorldPos"].xyz (PHONG_4POINT only)
+};
+static_assert(sizeof(VOut) == 64, "VOut must be 64 bytes");
+
+// Triangle setup record: what RasterizeTriangle (Rasterizer.cs:401-460) has in locals when
+// it enters the tile loop.  Vertex order is the reference's outputs[] order {v2, v1, v0}.
+struct TriRec {
+    float sx[3], sy[3];     // screen[0..2]
+    float depth[3];         // depths[0..2]
+    float inv_area;         // 1 / EdgeFunction(s0,s1,s2)
+    uint32_t vref[3];       // index of outputs[0..2] in the VOut array (clip pool follows the VS outputs)
+    uint32_t bbox_x;        // minX | maxX << 16   (pixel bbox, already clamped to the frame)
+    uint32_t bbox_y;        // minY | maxY << 16
+    uint32_t draw_flags;    // draw index | (outputs[0].Interpolate ? 1u<<31 : 0)
+};
+static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
+
+// Per-draw constants (one RenderMesh call), read with scalar loads.
+struct DrawParams {
+    float model[16], view[16], proj[16];
+    swr_uniforms u;
+    const swr_vertex* verts;
+    const uint16_t* idx;
+    const uint8_t* tex;
+    int tex_w, tex_h;
+    int program, cull, depth_test, blend;
+    uint32_t n_verts, n_tris;
+    uint32_t vert_base;     // first VOut of this draw
+    uint32_t tri_base;      // first global triangle number of this draw
+};
+
+struct Counters {           // device-side swr_stats accumulators
+    unsigned long long triangles_in, triangles_setup, triangles_clipped;
+    unsigned long long fragments_tested, fragments_shaded, fragments_written;
+    unsigned long long tile_pairs;
+    unsigned int overflow;  // set when a tile list did not fit
+    unsigned int pad;
+};
+
+struct FrameParams {
+    int width, height;          // full frame
+    int tiles_x, tiles_y;       // full frame, in 16x16 tiles
+    int band_ty0, band_ty1;     // this context renders tile rows [band_ty0, band_ty1)
+    int band_y0;                // = band_ty0 * 16: first pixel row stored in the buffers
+    int band_rows;              // pixel rows stored
+    float near_clip;
+};
+
+// ---------------------------------------------------------------- .NET scalar semantics ----
+__device__ __forceinline__ bool is_neg_bits(float f) { return (__float_as_uint(f) >> 31) != 0u; }
+__device__ __forceinline__ bool is_nan(float f) { return f != f; }
+__device__ __forceinline__ bool is_nan_or_inf(float f) { return (__float_as_uint(f) & 0x7f800000u) == 0x7f800000u; }
+
+// (int)float, .NET 9 x64: saturating, NaN -> 0
+__device__ __forceinline__ int f2i(float f) {
+    int r = (int)fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);   // in-range part (fmaxf/fminf drop NaN)
+    r = (f >= 2147483648.0f) ? 2147483647 : r;
+    r = is_nan(f) ? 0 : r;
+    return r;
+}
+// MathF.Min / MathF.Max: NaN-propagating, -0 < +0
+__device__ __forceinline__ float mathf_min(float a, float b) {
+    if (a != b) { if (!is_nan(a)) return a < b ? a : b; return a; }
+    return is_neg_bits(a) ? a : b;
+}
+__device__ __forceinline__ float mathf_max(float a, float b) {
+    if (a != b) { if (!is_nan(a)) return b < a ? a : b; return a; }
+    return is_neg_bits(b) ? a : b;
+}
+__device__ __forceinline__ float math_clamp(float v, float lo, float hi) {   // Math.Clamp
+    if (v < lo) return lo;
+    else if (v > hi) return hi;
+    return v;
+}
+
+// ---------------------------------------------------------------- System.Numerics ----
+__device__ __forceinline__ float nm_madd(float a, float b, float c) {
+#if SWR_NUMERICS_FMA
+    return __builtin_fmaf(a, b, c);
+#else
+    float p = a * b;
+    return p + c;
+#endif
+}
+// Vector4.Transform(v, M): ((x*row1 + y*row2) + z*row3) + w*row4 ; M row-major M11..M44
+__device__ __forceinline__ void vec4_transform(const float v[4], const float* __restrict__ m, float out[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r = m[j] * v[0];
+        r = nm_madd(m[4 + j], v[1], r);
+        r = nm_madd(m[8 + j], v[2], r);
+        r = nm_madd(m[12 + j], v[3], r);
+        out[j] = r;
+    }
+}
+__device__ __forceinline__ void vec3_transform_normal(const float n[3], const float* __restrict__ m, float out[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float r = m[j] * n[0];
+        r = nm_madd(m[4 + j], n[1], r);
+        r = nm_madd(m[8 + j], n[2], r);
+        out[j] = r;
+    }
+}
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+    return (ax * bx + ay * by) + az * bz;
+}
+__device__ __forceinline__ float nm_lerp(float a, float b, float t) {   // a*(1-t) + b*t
+#if SWR_NUMERICS_FMA
+    return __builtin_fmaf(a, 1.0f - t, b * t);
+#else
+    float x = a * (1.0f - t);
+    float y = b * t;
+    return x + y;
+#endif
+}
+
+// EdgeFunction, Rasterizer.cs:562-563
+__device__ __forceinline__ float edge_function(float ax, float ay, float bx, float by, float cx, float cy) {
+    float p = (cx - ax) * (by - ay);
+    float q = (cy - ay) * (bx - ax);
+    return p - q;
+}
+
+// GetDepthTestFunction, Rasterizer.cs:543-559
+__device__ __forceinline__ bool depth_func(int test, float nd, float od) {
+    switch (test) {
+    case SWR_DEPTH_LESSEQUAL:    return nd >= od;
+    case SWR_DEPTH_LESS:         return nd > od;
+    case SWR_DEPTH_GREATER:      return nd < od;
+    case SWR_DEPTH_GREATEREQUAL: return nd <= od;
+    case SWR_DEPTH_EQUAL:        return fabsf(nd - od) < SWR_EPSILON;
+    case SWR_DEPTH_NOTEQUAL:     return fabsf(nd - od) >= SWR_EPSILON;
+    default:                     return true;    // Disabled, Always, anything else
+    }
+}
+
+// Blend, Rasterizer.cs:58-65
+__device__ __forceinline__ float4 blend(float4 s, float4 d, int mode) {
+    float4 o;
+    switch (mode) {
+    case SWR_BLEND_ALPHA: {
+        float a = s.w, ia = 1.0f - s.w;
+        float x;
+        x = s.x * a; o.x = x + d.x * ia;
+        x = s.y * a; o.y = x + d.y * ia;
+        x = s.z * a; o.z = x + d.z * ia;
+        x = s.w * a; o.w = x + d.w * ia;
+        return o; }
+    case SWR_BLEND_ADDITIVE:
+        o.x = mathf_min(s.x + d.x, 1.0f); o.y = mathf_min(s.y + d.y, 1.0f);
+        o.z = mathf_min(s.z + d.z, 1.0f); o.w = mathf_min(s.w + d.w, 1.0f);
+        return o;
+    case SWR_BLEND_MULTIPLY:
+        o.x = s.x * d.x; o.y = s.y * d.y; o.z = s.z * d.z; o.w = s.w * d.w;
+        return o;
+    default:
+        return s;
+    }
+}
+
+// Texture.Sample, Texture.cs:43-63 -- nearest, wrap; texels RGBA8 row-major
+__device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
+    float u = tu - (float)f2i(tu);
+    float v = tv - (float)f2i(tv);
+    u += (u < 0) ? 1.0f : 0.0f;
+    v += (v < 0) ? 1.0f : 0.0f;
+    int xi = f2i(u * (float)w);
+    int yi = f2i(v * (float)h);
+    // C# '%' truncates toward zero; the common case 0 <= xi <= w needs no integer division
+    int x = (xi >= 0 && xi < w) ? xi : (xi == w ? 0 : xi % w);
+    int y = (yi >= 0 && yi < h) ? yi : (yi == h ? 0 : yi % h);
+    if (x < 0) x += w;
+    if (y < 0) y += h;
+    uint32_t p = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)y * (size_t)w + (size_t)x));
+    const float inv255 = 1.0f / 255.0f;
+    float4 o;
+    o.x = (float)(p & 0xffu) * inv255;
+    o.y = (float)((p >> 8) & 0xffu) * inv255;
+    o.z = (float)((p >> 16) & 0xffu) * inv255;
+    o.w = (float)(p >> 24) * inv255;
+    return o;
+}
+
+}  // namespace swr

@@ -1,0 +1,238 @@
+// swr_geometry.hip.h -- vertex stage and triangle setup (near clip, viewport, cull, bbox) for gfx950.
+//
+// Reference path restated here (file:line under the C# repo):
+//   Renderer.VertexShader              Renderer.cs:830-846
+//   RenderMesh per-triangle body       Rasterizer.cs:200-229
+//   ClipTriangleAgainstNearPlane       Rasterizer.cs:95-160   (+ Shaders.Lerp, Shaders.cs:50-95)
+//   DrawTriangle                       Rasterizer.cs:342-399
+//   RasterizeTriangle prologue         Rasterizer.cs:411-452
+//
+// The reference runs the vertex shader three times per triangle (six counting the dead
+// avgDepth pre-pass, Rasterizer.cs:184-197); the shader is a pure function of the vertex,
+// so running it once per unique vertex gives bit-identical varyings.
+#pragma once
+#include "swr_device.h"
+
+namespace swr {
+
+// one 256-thread block handles up to 256 consecutive vertices / triangles of ONE draw,
+// so the draw's matrices are wave-uniform (scalar loads)
+struct BlockMap { uint32_t draw; uint32_t first; };
+
+__global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ draws,
+                                                const BlockMap* __restrict__ blocks,
+                                                VOut* __restrict__ vout) {
+    const BlockMap bm = blocks[blockIdx.x];
+    const DrawParams* __restrict__ dp = draws + bm.draw;
+    const uint32_t local = bm.first + threadIdx.x;
+    if (local >= dp->n_verts) return;
+
+    const float* __restrict__ vin = reinterpret_cast<const float*>(dp->verts + local);
+    // 48-byte vertex = three 16-byte loads
+    const float4 q0 = *reinterpret_cast<const float4*>(vin);       // pos.xyz, uv.x
+    const float4 q1 = *reinterpret_cast<const float4*>(vin + 4);   // uv.y, normal.xyz
+    const float4 q2 = *reinterpret_cast<const float4*>(vin + 8);   // color
+
+    float p[4] = { q0.x, q0.y, q0.z, 1.0f };
+    float world[4], viewp[4], clip[4];
+    vec4_transform(p, dp->model, world);        // Renderer.cs:832
+    vec4_transform(world, dp->view, viewp);     // :833
+    vec4_transform(viewp, dp->proj, clip);      // :834
+    float n[3] = { q1.y, q1.z, q1.w }, tn[3];
+    vec3_transform_normal(n, dp->model, tn);    // :835
+    float len = sqrtf(dot3(tn[0], tn[1], tn[2], tn[0], tn[1], tn[2]));   // Vector3.Normalize = v / Length()
+
+    float4* o = reinterpret_cast<float4*>(vout + dp->vert_base + local);
+    o[0] = make_float4(clip[0], clip[1], clip[2], clip[3]);
+    o[1] = q2;
+    o[2] = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
+    o[3] = make_float4(tn[2] / len, world[0], world[1], world[2]);
+}
+
+// a vertex moving through clip + setup: the stored varyings plus the Interpolate flag
+struct SVert { VOut v; bool interp; };
+
+__device__ __forceinline__ void svert_lerp(const SVert& a, const SVert& b, float t, SVert& r) {
+    // Shaders.Lerp(a, b, t, interpolate: true), Shaders.cs:50-95 (the clipper always passes true)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v.clip[i] = nm_lerp(a.v.clip[i], b.v.clip[i], t);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r.v.uv[i] = nm_lerp(a.v.uv[i], b.v.uv[i], t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v.color[i] = nm_lerp(a.v.color[i], b.v.color[i], t);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.v.wn[i] = nm_lerp(a.v.wn[i], b.v.wn[i], t);      // no renormalisation, :72-73
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.v.wpos[i] = nm_lerp(a.v.wpos[i], b.v.wpos[i], t);
+    r.interp = true;
+}
+
+__device__ __forceinline__ void store_vout(VOut* __restrict__ dst, const VOut& v) {
+    float4* o = reinterpret_cast<float4*>(dst);
+    o[0] = make_float4(v.clip[0], v.clip[1], v.clip[2], v.clip[3]);
+    o[1] = make_float4(v.color[0], v.color[1], v.color[2], v.color[3]);
+    o[2] = make_float4(v.uv[0], v.uv[1], v.wn[0], v.wn[1]);
+    o[3] = make_float4(v.wn[2], v.wpos[0], v.wpos[1], v.wpos[2]);
+}
+__device__ __forceinline__ void load_vout(const VOut* __restrict__ src, VOut& v) {
+    const float4* s = reinterpret_cast<const float4*>(src);
+    float4 a = s[0], b = s[1], c = s[2], d = s[3];
+    v.clip[0] = a.x; v.clip[1] = a.y; v.clip[2] = a.z; v.clip[3] = a.w;
+    v.color[0] = b.x; v.color[1] = b.y; v.color[2] = b.z; v.color[3] = b.w;
+    v.uv[0] = c.x; v.uv[1] = c.y; v.wn[0] = c.z; v.wn[1] = c.w;
+    v.wn[2] = d.x; v.wpos[0] = d.y; v.wpos[1] = d.z; v.wpos[2] = d.w;
+}
+
+#define SWR_TB_INVALID 0xffffffffffffffffull
+
+// DrawTriangle + RasterizeTriangle prologue for one (possibly clipped) triangle.
+// v0,v1,v2 in submission order; r0,r1,r2 their VOut indices.  Returns true and fills the
+// record when the triangle reaches the tile loop.
+__device__ __forceinline__ bool setup_triangle(const FrameParams& fp, int cull, uint32_t draw,
+                                               const SVert& v0, const SVert& v1, const SVert& v2,
+                                               uint32_t r0, uint32_t r1, uint32_t r2,
+                                               TriRec* __restrict__ rec, unsigned long long* __restrict__ tb) {
+    const int rw = fp.width, rh = fp.height;
+    // outputs = { v2, v1, v0 }  (Rasterizer.cs:367)
+    const SVert* o[3] = { &v2, &v1, &v0 };
+    float sx[3], sy[3], dz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float invW = 1.0f / o[i]->v.clip[3];                        // :371
+        float nx = o[i]->v.clip[0] * invW, ny = o[i]->v.clip[1] * invW, nz = o[i]->v.clip[2] * invW;
+        if (is_nan_or_inf(nx) || is_nan_or_inf(ny) || is_nan_or_inf(nz)) return false;   // :378-380
+        sx[i] = (nx * 0.5f + 0.5f) * (float)rw;                     // :383-386
+        sy[i] = (1.0f - (ny * 0.5f + 0.5f)) * (float)rh;
+        dz[i] = (nz + 1.0f) * 0.5f;                                 // :388
+    }
+    if (v0.v.clip[3] == 0 || v1.v.clip[3] == 0 || v2.v.clip[3] == 0) return false;       // :393
+    float area = edge_function(sx[0], sy[0], sx[1], sy[1], sx[2], sy[2]);                // :396, :411
+    if (area == 0) return false;
+    bool front = area < 0;                                                               // :414
+    if ((cull == SWR_CULL_BACK && !front) || (cull == SWR_CULL_FRONT && front)) return false;
+    float inv_area = 1.0f / area;                                                        // :427
+
+    float minXf = mathf_min(mathf_min(sx[0], sx[1]), sx[2]);                             // :432-435
+    float maxXf = mathf_max(mathf_max(sx[0], sx[1]), sx[2]);
+    float minYf = mathf_min(mathf_min(sy[0], sy[1]), sy[2]);
+    float maxYf = mathf_max(mathf_max(sy[0], sy[1]), sy[2]);
+    int minX = max(f2i(floorf(minXf)), 0);                                               // :437-440
+    int maxX = min(f2i(ceilf(maxXf)), rw - 1);
+    int minY = max(f2i(floorf(minYf)), 0);
+    int maxY = min(f2i(ceilf(maxYf)), rh - 1);
+    if (minX > maxX || minY > maxY) return false;                                        // :442
+
+    float4* out = reinterpret_cast<float4*>(rec);
+    out[0] = make_float4(sx[0], sx[1], sx[2], sy[0]);
+    out[1] = make_float4(sy[1], sy[2], dz[0], dz[1]);
+    out[2] = make_float4(dz[2], inv_area, __uint_as_float(r2), __uint_as_float(r1));    // vref = outputs order
+    out[3] = make_float4(__uint_as_float(r0),
+                         __uint_as_float((uint32_t)minX | ((uint32_t)maxX << 16)),
+                         __uint_as_float((uint32_t)minY | ((uint32_t)maxY << 16)),
+                         __uint_as_float(draw | (o[0]->interp ? 0x80000000u : 0u)));
+    // tile bbox (Rasterizer.cs:449-452), 16 bits each: tminx | tmaxx<<16 | tminy<<32 | tmaxy<<48
+    *tb = (unsigned long long)(minX / SWR_TILE) | ((unsigned long long)(maxX / SWR_TILE) << 16) |
+          ((unsigned long long)(minY / SWR_TILE) << 32) | ((unsigned long long)(maxY / SWR_TILE) << 48);
+    return true;
+}
+
+// One thread per submitted triangle.  Slot 2*t is the triangle itself (or the first fan
+// triangle of its clipped polygon), slot 2*t+1 the second fan triangle; slots keep
+// submission order, which the per-tile lists preserve.
+__global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ draws,
+                                               const BlockMap* __restrict__ blocks,
+                                               const VOut* __restrict__ vout_ro,
+                                               VOut* __restrict__ clip_pool,     // 4 VOut per triangle, indexed by global triangle
+                                               uint32_t clip_pool_base,          // VOut index of clip_pool[0]
+                                               TriRec* __restrict__ recs,
+                                               unsigned long long* __restrict__ slot_tb,
+                                               FrameParams fp,
+                                               Counters* __restrict__ counters /* 64 replicas */) {
+    const BlockMap bm = blocks[blockIdx.x];
+    const DrawParams* __restrict__ dp = draws + bm.draw;
+    const uint32_t local = bm.first + threadIdx.x;
+    const bool active = local < dp->n_tris;
+    unsigned n_setup = 0, n_clipped = 0;
+
+    if (active) {
+        const uint32_t gt = dp->tri_base + local;
+        const uint32_t slot = 2u * gt;
+        unsigned long long tb0 = SWR_TB_INVALID, tb1 = SWR_TB_INVALID;
+
+        const uint16_t* __restrict__ ip = dp->idx + 3u * local;
+        const uint32_t r0 = dp->vert_base + ip[0], r1 = dp->vert_base + ip[1], r2 = dp->vert_base + ip[2];
+        SVert v[3];
+        load_vout(vout_ro + r0, v[0].v);
+        load_vout(vout_ro + r1, v[1].v);
+        load_vout(vout_ro + r2, v[2].v);
+        const bool interp = dp->program != SWR_PROG_FLAT_COLOR;
+        v[0].interp = v[1].interp = v[2].interp = interp;
+
+        const bool b0 = v[0].v.clip[3] <= 0, b1 = v[1].v.clip[3] <= 0, b2 = v[2].v.clip[3] <= 0;   // :208-210
+        if (!(b0 && b1 && b2)) {                                                                   // :212
+            if (b0 || b1 || b2) {                                                                  // :217
+                n_clipped = 1;
+                // ClipTriangleAgainstNearPlane, Rasterizer.cs:95-160
+                SVert poly[4];
+                int n = 0;
+                const float nearc = fp.near_clip;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const SVert& cur = v[i];
+                    const SVert& nxt = v[(i + 1) % 3];
+                    bool cur_in = cur.v.clip[2] >= nearc * cur.v.clip[3];                          // :112-113
+                    bool nxt_in = nxt.v.clip[2] >= nearc * nxt.v.clip[3];
+                    if (cur_in) { poly[n & 3] = cur; ++n; }
+                    if (cur_in != nxt_in) {
+                        float z0 = cur.v.clip[2], w0 = cur.v.clip[3], z1 = nxt.v.clip[2], w1 = nxt.v.clip[3];
+                        float denom = (z1 - z0) - nearc * (w1 - w0);                               // :131
+                        float t;
+                        if (fabsf(denom) < SWR_EPSILON) {
+                            t = 0.5f;
+                        } else {
+                            t = (z0 - nearc * w0) / (nearc * (w1 - w0) - (z1 - z0));               // :138
+                            t = math_clamp(t, 0.0f, 1.0f);
+                        }
+                        svert_lerp(cur, nxt, t, poly[n & 3]); ++n;                                 // :142
+                    }
+                }
+                if (n >= 3) {                                                                      // :148
+                    VOut* pool = clip_pool + 4ull * gt;
+                    const uint32_t pbase = clip_pool_base + 4u * gt;
+                    for (int k = 0; k < n; ++k) store_vout(pool + k, poly[k].v);
+                    // fan (0, k, k+1), Rasterizer.cs:154-157
+                    if (setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[1], poly[2],
+                                       pbase, pbase + 1, pbase + 2, recs + slot, &tb0)) ++n_setup;
+                    if (n == 4 && setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[2], poly[3],
+                                                 pbase, pbase + 2, pbase + 3, recs + slot + 1, &tb1)) ++n_setup;
+                }
+            } else {
+                if (setup_triangle(fp, dp->cull, bm.draw, v[0], v[1], v[2], r0, r1, r2, recs + slot, &tb0)) ++n_setup;
+            }
+        }
+        slot_tb[slot] = tb0;
+        slot_tb[slot + 1] = tb1;
+    }
+
+    // block-level counter reduction, then one atomic per counter per block into a replica
+    __shared__ unsigned s_cnt[3];
+    if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long act_mask = __ballot(active);
+    unsigned long long set_mask1 = __ballot(n_setup >= 1), set_mask2 = __ballot(n_setup >= 2);
+    unsigned long long clip_mask = __ballot(n_clipped != 0);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_cnt[0], (unsigned)__popcll(act_mask));
+        atomicAdd(&s_cnt[1], (unsigned)(__popcll(set_mask1) + __popcll(set_mask2)));
+        atomicAdd(&s_cnt[2], (unsigned)__popcll(clip_mask));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Counters* c = counters + (blockIdx.x & 63);
+        atomicAdd(&c->triangles_in, (unsigned long long)s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&c->triangles_setup, (unsigned long long)s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&c->triangles_clipped, (unsigned long long)s_cnt[2]);
+    }
+}
+
+}  // namespace swr

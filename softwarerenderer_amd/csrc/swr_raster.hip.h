@@ -1,0 +1,398 @@
+// swr_raster.hip.h -- per-tile rasterise / depth-test / shade / blend kernel for gfx950.
+//
+// Reference path restated here (file:line under the C# repo):
+//   RasterizeTriangle tile loop   Rasterizer.cs:462-538
+//   GetDepthTestFunction          Rasterizer.cs:543-559
+//   Interpolate / InterpolateData Rasterizer.cs:566-707
+//   Renderer.FragmentShader       Renderer.cs:848-860
+//   Texture.Sample                Texture.cs:43-63
+//   Blend                         Rasterizer.cs:58-65
+//
+// Mapping: ONE WAVE OWNS ONE 16x16 TILE (the reference's lock granule).  Lane l holds the
+// four pixels x = 4*(l&3)..+3 of row y = l>>2; colour and Z of the tile stay in registers for
+// the whole triangle list, so every pixel is read at most once and written exactly once per
+// flush (clear fused into the tile init) and no atomics or locks are needed.  Triangles are
+// walked in list (= submission) order, which reproduces the serial schedule of the reference
+// for depth ties and blending.
+//
+// Exact edge values: the reference steps w0,w1,w2 incrementally in float32 from the tile's
+// bbox-clipped origin (Rasterizer.cs:481-483,527-534); 40% of the values differ from direct
+// evaluation at 4096^2, and depth is a function of them, so the add chain
+// is replayed: (y - startY) row steps, then (x - startX) column steps, each a rounded f32 add.
+#pragma once
+#include "swr_device.h"
+
+namespace swr {
+
+struct RasterArgs {
+    FrameParams fp;
+    const TriRec* __restrict__ recs;
+    const VOut* __restrict__ vout;
+    const DrawParams* __restrict__ draws;
+    const uint32_t* __restrict__ tile_start;
+    const uint32_t* __restrict__ tile_count;
+    const uint32_t* __restrict__ tile_list;
+    float4* __restrict__ color;
+    float* __restrict__ depth;
+    uint32_t* __restrict__ tile_stats;     // 3 x u32 per tile: tested, shaded, written (accumulated)
+    float clear_rgba[4];
+    int clear_color_on, clear_depth_on;
+    int blocks_x, blocks_y;                // grid of 2x2-tile workgroups over the band
+};
+
+// fragment inputs a built-in program may read
+struct Frag {
+    float clip_z;
+    float4 color;
+    float u, v;
+    float wn[3];
+    float wpos[3];
+};
+
+// Renderer.FragmentShader, Renderer.cs:848-860
+__device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, const Frag& f) {
+    const swr_uniforms& u = dp->u;
+    float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
+                                          -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
+    float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (dp->tex) tc = texture_sample(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
+    float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
+    fog = (fog * fog) * (3.0f - 2.0f * fog);
+    float s = 0.1f + 0.9f * diffuse;
+    float4 o;
+    o.x = nm_lerp(u.fog_color[0], (base.x * s) * u.light_color[0], fog);
+    o.y = nm_lerp(u.fog_color[1], (base.y * s) * u.light_color[1], fog);
+    o.z = nm_lerp(u.fog_color[2], (base.z * s) * u.light_color[2], fog);
+    o.w = base.w;
+    return o;
+}
+
+// PHONG_4POINT: build-defined, no reference semantics (see oracle/swr_oracle.c fs_phong4 for the formula)
+__device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, const Frag& f) {
+    const swr_uniforms& u = dp->u;
+    float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (dp->tex) tc = texture_sample(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    float base[4] = { f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w };
+    float Vd[3] = { u.camera_position[0] - f.wpos[0], u.camera_position[1] - f.wpos[1], u.camera_position[2] - f.wpos[2] };
+    float vl = sqrtf(dot3(Vd[0], Vd[1], Vd[2], Vd[0], Vd[1], Vd[2]));
+    float V[3] = { Vd[0] / vl, Vd[1] / vl, Vd[2] / vl };
+    float acc[3] = { 0.1f * base[0], 0.1f * base[1], 0.1f * base[2] };
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const swr_point_light& L = u.lights[l];
+        float Ld[3] = { L.position[0] - f.wpos[0], L.position[1] - f.wpos[1], L.position[2] - f.wpos[2] };
+        float dist = sqrtf(dot3(Ld[0], Ld[1], Ld[2], Ld[0], Ld[1], Ld[2]));
+        float Ln[3] = { Ld[0] / dist, Ld[1] / dist, Ld[2] / dist };
+        float ndotl = mathf_max(0.0f, dot3(f.wn[0], f.wn[1], f.wn[2], Ln[0], Ln[1], Ln[2]));
+        float att = math_clamp(1.0f - dist / L.range, 0.0f, 1.0f);
+        att = att * att;
+        float Hd[3] = { Ln[0] + V[0], Ln[1] + V[1], Ln[2] + V[2] };
+        float hl = sqrtf(dot3(Hd[0], Hd[1], Hd[2], Hd[0], Hd[1], Hd[2]));
+        float H[3] = { Hd[0] / hl, Hd[1] / hl, Hd[2] / hl };
+        float sp = mathf_max(0.0f, dot3(f.wn[0], f.wn[1], f.wn[2], H[0], H[1], H[2]));
+        sp = sp * sp; sp = sp * sp; sp = sp * sp; sp = sp * sp;
+        float k = L.intensity * att;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float term = (base[i] * ndotl + sp) * (L.color[i] * k);
+            acc[i] = acc[i] + term;
+        }
+    }
+    return make_float4(acc[0], acc[1], acc[2], base[3]);
+}
+
+// Rasterizer.Interpolate for the varyings `program` reads, then the fragment program.
+// A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.
+__device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, int program, bool interp,
+                                                 const VOut* __restrict__ A, const VOut* __restrict__ B,
+                                                 const VOut* __restrict__ C, float w0f, float w1f, float w2f) {
+    const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
+    if (simple && !interp) return make_float4(A->color[0], A->color[1], A->color[2], A->color[3]);   // :622-627
+
+    float ra = w0f / A->clip[3];            // :576-578
+    float rb = w1f / B->clip[3];
+    float rc = w2f / C->clip[3];
+    float inv_sum = (ra + rb) + rc;         // :579
+    float w = 1.0f / inv_sum;               // :582
+#define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
+    Frag f;
+    if (interp) {
+        f.color = make_float4(SWR_PERSP(A->color[0], B->color[0], C->color[0]), SWR_PERSP(A->color[1], B->color[1], C->color[1]),
+                              SWR_PERSP(A->color[2], B->color[2], C->color[2]), SWR_PERSP(A->color[3], B->color[3], C->color[3]));
+    } else {
+        f.color = make_float4(A->color[0], A->color[1], A->color[2], A->color[3]);
+    }
+    if (simple) return f.color;
+
+    f.clip_z = SWR_PERSP(A->clip[2], B->clip[2], C->clip[2]);
+    f.u = SWR_PERSP(A->uv[0], B->uv[0], C->uv[0]);
+    f.v = SWR_PERSP(A->uv[1], B->uv[1], C->uv[1]);
+#undef SWR_PERSP
+    if (interp) {
+        float wa = ra * w, wb = rb * w, wc = rc * w;      // :583-585
+        // InterpolateData, Vector3 key: weighted sum with the NORMALISED weights, then renormalise (:680-688)
+        float n0 = (A->wn[0] * wa + B->wn[0] * wb) + C->wn[0] * wc;
+        float n1 = (A->wn[1] * wa + B->wn[1] * wb) + C->wn[1] * wc;
+        float n2 = (A->wn[2] * wa + B->wn[2] * wb) + C->wn[2] * wc;
+        float len_sq = dot3(n0, n1, n2, n0, n1, n2);
+        if (len_sq > 1e-6f) {
+            float s = 1.0f / sqrtf(len_sq);
+            n0 = n0 * s; n1 = n1 * s; n2 = n2 * s;
+        }
+        f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
+        if (program == SWR_PROG_PHONG_4POINT) {           // Vector4 key: weighted sum only (:690-693)
+            f.wpos[0] = (A->wpos[0] * wa + B->wpos[0] * wb) + C->wpos[0] * wc;
+            f.wpos[1] = (A->wpos[1] * wa + B->wpos[1] * wb) + C->wpos[1] * wc;
+            f.wpos[2] = (A->wpos[2] * wa + B->wpos[2] * wb) + C->wpos[2] * wc;
+        }
+    } else {
+        f.wn[0] = A->wn[0]; f.wn[1] = A->wn[1]; f.wn[2] = A->wn[2];
+        f.wpos[0] = A->wpos[0]; f.wpos[1] = A->wpos[1]; f.wpos[2] = A->wpos[2];
+    }
+    if (program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
+    return fs_dust2(dp, f);
+}
+
+__global__ __launch_bounds__(256) void k_raster(RasterArgs a) {
+    // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tile blocks so that neighbouring tiles' triangle records hit the same L2.
+    // Bijective for any grid size; placement only affects speed.
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;
+    const uint32_t blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + kk;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bx = (int)(blk % (uint32_t)a.blocks_x), by = (int)(blk / (uint32_t)a.blocks_x);
+    const int tx = bx * 2 + (wave & 1);
+    const int ty_local = by * 2 + (wave >> 1);
+    const int ty = a.fp.band_ty0 + ty_local;
+    if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
+    const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
+    const uint32_t n = a.tile_count[tile];
+    if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
+    const uint32_t start = a.tile_start[tile];
+
+    const int W = a.fp.width, H = a.fp.height;
+    const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
+    const int row = lane >> 2, quad = lane & 3;
+    const int py = y0 + row;
+    const int pxb = x0 + quad * 4;               // first of this lane's four pixels
+    const int tile_end_x = min(x0 + SWR_TILE - 1, W - 1), tile_end_y = min(y0 + SWR_TILE - 1, H - 1);
+    const size_t rowbase = (size_t)(py - a.fp.band_y0) * (size_t)W;
+
+    float4 col[4];
+    float z[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool inb = (pxb + j) < W && py < H;
+        if (a.clear_color_on) col[j] = make_float4(a.clear_rgba[0], a.clear_rgba[1], a.clear_rgba[2], a.clear_rgba[3]);
+        else col[j] = inb ? a.color[rowbase + pxb + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.clear_depth_on) z[j] = SWR_FLOAT_MINVALUE;
+        else z[j] = inb ? a.depth[rowbase + pxb + j] : SWR_FLOAT_MINVALUE;
+    }
+    unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_list[start + i]);
+        const TriRec* __restrict__ rp = a.recs + slot;
+        const float s0x = rp->sx[0], s1x = rp->sx[1], s2x = rp->sx[2];
+        const float s0y = rp->sy[0], s1y = rp->sy[1], s2y = rp->sy[2];
+        const uint32_t bbx = rp->bbox_x, bby = rp->bbox_y;
+        const int minX = (int)(bbx & 0xffffu), maxX = (int)(bbx >> 16);
+        const int minY = (int)(bby & 0xffffu), maxY = (int)(bby >> 16);
+
+        const int startX = max(minX, x0), endX = min(maxX, tile_end_x);        // :471-474
+        const int startY = max(minY, y0), endY = min(maxY, tile_end_y);
+        if (startX > endX || startY > endY) continue;                          // :476
+
+        const float a01 = s0y - s1y, b01 = s1x - s0x;                          // :445-447
+        const float a12 = s1y - s2y, b12 = s2x - s1x;
+        const float a20 = s2y - s0y, b20 = s0x - s2x;
+        const float fsx = (float)startX, fsy = (float)startY;
+        float w0 = a12 * (fsx - s1x) + b12 * (fsy - s1y);                      // :481-483
+        float w1 = a20 * (fsx - s2x) + b20 * (fsy - s2y);
+        float w2 = a01 * (fsx - s0x) + b01 * (fsy - s0y);
+
+        // row chain: wRow += b, (py - startY) times  (:532-534)
+        const int nrow = py - startY;
+        const int nrow_max = endY - startY;
+        for (int k = 0; k < nrow_max; ++k) {
+            if (k < nrow) { w0 += b12; w1 += b20; w2 += b01; }
+        }
+        // column chain up to this lane's first pixel: w += a, (pxb - startX) times  (:527-529)
+        const int npre = pxb - startX;
+        const int npre_max = min(12, endX - startX);
+        for (int k = 0; k < npre_max; ++k) {
+            if (k < npre) { w0 += a12; w1 += a20; w2 += a01; }
+        }
+        const bool rowok = py >= startY && py <= endY;
+        bool inside[4];
+        float e0[4], e1[4], e2[4];
+        bool any_inside = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int px = pxb + j;
+            e0[j] = w0; e1[j] = w1; e2[j] = w2;
+            const bool valid = rowok && px >= startX && px <= endX;
+            inside[j] = valid && ((w0 >= 0 && w1 >= 0 && w2 >= 0) || (w0 <= 0 && w1 <= 0 && w2 <= 0));   // :493-494
+            any_inside = any_inside || inside[j];
+            // x + (-0.0f) == x for every x, so lanes left of startX keep the row value unchanged
+            const bool step = px >= startX;
+            w0 += step ? a12 : -0.0f; w1 += step ? a20 : -0.0f; w2 += step ? a01 : -0.0f;
+        }
+        if (!__any(any_inside)) continue;
+
+        const float d0 = rp->depth[0], d1 = rp->depth[1], d2 = rp->depth[2];
+        const float inv_area = rp->inv_area;
+        const uint32_t dflags = rp->draw_flags;
+        const DrawParams* __restrict__ dp = a.draws + (dflags & 0x7fffffffu);
+        const bool interp = (dflags >> 31) != 0u;
+        const int program = dp->program, depth_test = dp->depth_test, blend_mode = dp->blend;
+        const VOut* __restrict__ A = a.vout + rp->vref[0];
+        const VOut* __restrict__ B = a.vout + rp->vref[1];
+        const VOut* __restrict__ C = a.vout + rp->vref[2];
+
+        bool pass[4], alpha_ok[4];
+        float dep[4];
+        float4 src[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pass[j] = false; alpha_ok[j] = false; dep[j] = 0.0f;
+            src[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (inside[j]) {
+                const float w0f = e0[j] * inv_area, w1f = e1[j] * inv_area, w2f = e2[j] * inv_area;   // :498-500
+                const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                     // :502
+                dep[j] = d;
+                if (depth_func(depth_test, d, z[j])) {                                                // :505
+                    pass[j] = true;
+                    src[j] = shade_fragment(dp, program, interp, A, B, C, w0f, w1f, w2f);             // :507-509
+                    alpha_ok[j] = src[j].w > 0.0f;                                                    // :511
+                }
+            }
+        }
+
+        if (blend_mode == SWR_BLEND_NONE) {
+            // canEarlyOut (:520-523): the first fragment of a row (within this tile) that passes depth
+            // but fails alpha ends the row: nothing to its right is visited.
+            int first_fail = 4;
+#pragma unroll
+            for (int j = 3; j >= 0; --j) if (pass[j] && !alpha_ok[j]) first_fail = j;
+            const unsigned long long fm = __ballot(first_fail < 4);
+            const unsigned rowbits = (unsigned)(fm >> (row * 4)) & 0xfu;
+            const bool killed_by_left = (rowbits & ((1u << quad) - 1u)) != 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (killed_by_left || j > first_fail) { inside[j] = false; pass[j] = false; alpha_ok[j] = false; }
+            }
+        }
+
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            n_tested += inside[j] ? 1u : 0u;
+            n_shaded += pass[j] ? 1u : 0u;
+            if (pass[j] && alpha_ok[j]) {
+                ++n_written;
+                col[j] = blend(src[j], col[j], blend_mode);                    // :513-515
+                if (depth_test != SWR_DEPTH_DISABLED) z[j] = dep[j];           // :517-518
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool inb = (pxb + j) < W && py < H;
+        if (inb) {
+            a.color[rowbase + pxb + j] = col[j];
+            a.depth[rowbase + pxb + j] = z[j];
+        }
+    }
+
+    // per-tile fragment counters: plain accumulate (this wave owns the tile)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_tested += (unsigned)__shfl_xor((int)n_tested, off);
+        n_shaded += (unsigned)__shfl_xor((int)n_shaded, off);
+        n_written += (unsigned)__shfl_xor((int)n_written, off);
+    }
+    if (lane == 0 && n > 0) {
+        uint32_t* ts = a.tile_stats + 3u * tile;
+        ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
+    }
+}
+
+// ---- small utility kernels -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_clear(float4* __restrict__ color, float* __restrict__ depth, size_t n,
+                                               float4 rgba, int do_color, int do_depth) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        if (do_color) color[i] = rgba;
+        if (do_depth) depth[i] = SWR_FLOAT_MINVALUE;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_texture_sample(const uint8_t* __restrict__ tex, int w, int h,
+                                                        const float2* __restrict__ uv, int n, float4* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = texture_sample(tex, w, h, uv[i].x, uv[i].y);
+}
+
+// sums the per-tile fragment counters; one block
+__global__ __launch_bounds__(1024) void k_reduce_tile_stats(const uint32_t* __restrict__ ts, uint32_t n_tiles,
+                                                            unsigned long long* __restrict__ out3) {
+    __shared__ unsigned long long s[3][16];
+    unsigned long long t[3] = { 0, 0, 0 };
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) { t[0] += ts[3 * i]; t[1] += ts[3 * i + 1]; t[2] += ts[3 * i + 2]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        unsigned lo = (unsigned)t[c], hi = (unsigned)(t[c] >> 32);
+        for (int off = 32; off > 0; off >>= 1) {
+            unsigned long long o = ((unsigned long long)(unsigned)__shfl_xor((int)hi, off) << 32) | (unsigned)__shfl_xor((int)lo, off);
+            t[c] += o; lo = (unsigned)t[c]; hi = (unsigned)(t[c] >> 32);
+        }
+        if ((threadIdx.x & 63) == 0) s[c][threadIdx.x >> 6] = t[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long sum = 0;
+        for (int wv = 0; wv < 16; ++wv) sum += s[threadIdx.x][wv];
+        out3[threadIdx.x] = sum;
+    }
+}
+
+// Rasterizer.Interpolate (public API, Rasterizer.cs:566-640), batched: one thread per weight triple.
+// verts: 3 records of 20 floats {clip4,color4,uv2,normal3,screen2,worldNormal3,pad2}
+// out:   n records of 24 floats {clip4,color4,uv2,normal3,screen2,worldNormal3,bary3,pad3}
+__global__ __launch_bounds__(256) void k_interpolate(const float* __restrict__ verts, const float* __restrict__ wts,
+                                                     int n, int interpolate, float* __restrict__ out) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* A = verts; const float* B = verts + 20; const float* C = verts + 40;
+    float w0 = wts[3 * i], w1 = wts[3 * i + 1], w2 = wts[3 * i + 2];
+    float ra = w0 / A[3], rb = w1 / B[3], rc = w2 / C[3];
+    float inv_sum = (ra + rb) + rc;
+    float w = 1.0f / inv_sum;
+    float wa = ra * w, wb = rb * w, wc = rc * w;
+    float* o = out + 24 * (size_t)i;
+#define SWR_PERSP_I(k_) ((((A[k_]) * ra + (B[k_]) * rb) + (C[k_]) * rc) * w)
+    for (int k = 0; k < 4; ++k) o[k] = SWR_PERSP_I(k);                 // ClipPosition
+    for (int k = 8; k < 10; ++k) o[k] = SWR_PERSP_I(k);                // TexCoord
+    for (int k = 13; k < 15; ++k) o[k] = SWR_PERSP_I(k);               // ScreenCoords
+    if (interpolate) {
+        for (int k = 4; k < 8; ++k) o[k] = SWR_PERSP_I(k);             // Color
+        for (int k = 10; k < 13; ++k) o[k] = SWR_PERSP_I(k);           // Normal
+        float v[3];
+        for (int k = 0; k < 3; ++k) v[k] = (A[15 + k] * wa + B[15 + k] * wb) + C[15 + k] * wc;
+        float len_sq = dot3(v[0], v[1], v[2], v[0], v[1], v[2]);
+        if (len_sq > 1e-6f) { float s = 1.0f / sqrtf(len_sq); v[0] = v[0] * s; v[1] = v[1] * s; v[2] = v[2] * s; }
+        o[15] = v[0]; o[16] = v[1]; o[17] = v[2];
+    } else {
+        for (int k = 4; k < 8; ++k) o[k] = A[k];
+        for (int k = 10; k < 13; ++k) o[k] = A[k];
+        for (int k = 15; k < 18; ++k) o[k] = A[k];
+    }
+#undef SWR_PERSP_I
+    o[18] = wa; o[19] = wb; o[20] = wc;
+    o[21] = o[22] = o[23] = 0.0f;
+}
+
+}  // namespace swr

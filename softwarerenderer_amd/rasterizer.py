@@ -1,0 +1,392 @@
+"""Host-side mirror of the reference's raster API over the HIP backend.
+
+Same names, argument meaning and error behaviour as the C# reference so that callers and
+tests read like the reference's own code (file:line under OCSYT/SoftwareRenderer):
+
+  Rasterizer.RenderMesh / InitializeTileLocks / Interpolate, enums, statics   Rasterizer.cs:14-50,69,163,566
+  Shaders.VertexInput / VertexOutput, shader delegates                        Shaders.cs:10-98
+  Texture(pixels) / Width / Height / Sample / Dispose                          Texture.cs:31-68
+  MainWindow.RenderWidth/RenderHeight/ColorBuffer/DepthBuffer/Get*/Set*/Clear* MainWindow.cs:25-31,378-436
+
+C# delegates cannot cross the C ABI: a `ShaderProgram` (program id + uniform block + texture)
+stands in for the (VertexShader, FragmentShader) delegate pair.  Everything below runs on the
+GPU through libswr_hip.so; nothing here computes pixels on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from typing import Optional
+
+import numpy as np
+
+from . import _native as N
+
+# numpy view of Shaders.VertexInput (Shaders.cs:10-24): 12 consecutive float32 = 48 bytes
+VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("uv", "<f4", 2), ("normal", "<f4", 3), ("color", "<f4", 4)])
+assert VERTEX_DTYPE.itemsize == 48 == C.sizeof(N.Vertex)
+
+
+class DebugMode(enum.IntEnum):      # Rasterizer.cs:14-18
+    None_ = 0
+    Wireframe = 1
+
+
+class BlendMode(enum.IntEnum):      # Rasterizer.cs:25-31
+    None_ = 0
+    Alpha = 1
+    Additive = 2
+    Multiply = 3
+
+
+class DepthTest(enum.IntEnum):      # Rasterizer.cs:33-43
+    Disabled = 0
+    Less = 1
+    LessEqual = 2
+    Greater = 3
+    GreaterEqual = 4
+    Equal = 5
+    NotEqual = 6
+    Always = 7
+
+
+class CullMode(enum.IntEnum):       # Rasterizer.cs:45-50
+    None_ = 0
+    Back = 1
+    Front = 2
+
+
+class Program(enum.IntEnum):        # built-in programs (include/swr.h)
+    FlatColor = 0
+    Gouraud = 1
+    Dust2LambertFog = 2
+    Phong4Point = 3
+
+
+def _f32(a, n=None):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))
+    if n is not None and arr.size != n:
+        raise ValueError(f"expected {n} floats, got {arr.size}")
+    return arr
+
+
+def _fptr(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_uniforms() -> N.Uniforms:
+    """Uniform defaults of Renderer.cs:39-44 (FogStart 1, FogEnd 25, FogColor, LightDirection, LightColor)."""
+    u = N.Uniforms()
+    u.light_direction[:] = euler_to_direction(-45.0, -45.0, 0.0)
+    u.light_color[:] = (1.0, 1.0, 1.0, 1.0)
+    u.fog_color[:] = (1.0, 0.62, 0.5, 1.0)
+    u.fog_start, u.fog_end = 1.0, 25.0
+    u.shininess = 16.0
+    return u
+
+
+def euler_to_direction(pitch_deg: float, yaw_deg: float, roll_deg: float):
+    """Renderer.EulerToDirection (Renderer.cs:967-972): -UnitZ rotated by CreateFromYawPitchRoll(yaw, pitch, roll),
+    normalised.  Host-side input generator (float32); roll does not move the forward axis."""
+    p = np.float32(pitch_deg) * np.float32(np.pi) / np.float32(180.0)
+    y = np.float32(yaw_deg) * np.float32(np.pi) / np.float32(180.0)
+    v = np.array([-np.sin(y) * np.cos(p), np.sin(p), -np.cos(y) * np.cos(p)], dtype=np.float32)
+    v = v / np.float32(np.sqrt(np.float32(v @ v)))
+    return tuple(float(t) for t in v)
+
+
+class Device:
+    """One swr_context = one GPU (one process per GPU)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = N.load()
+        self._ctx = C.c_void_p()
+        rc = self._lib.swr_create(int(device_id), C.byref(self._ctx))
+        if rc != N.SWR_OK:
+            msg = self._lib.swr_last_error(None)
+            raise N.SwrError(rc, msg.decode() if msg else "swr_create failed")
+
+    def close(self):
+        if self._ctx:
+            self._lib.swr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        N.check(self._ctx, rc)
+
+    @property
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._ck(self._lib.swr_device_name(self._ctx, buf, 256))
+        return buf.value.decode()
+
+    def stats(self) -> dict:
+        s = N.Stats()
+        self._ck(self._lib.swr_get_stats(self._ctx, C.byref(s)))
+        return {n: int(getattr(s, n)) for n, _ in N.Stats._fields_}
+
+    def reset_stats(self):
+        self._ck(self._lib.swr_reset_stats(self._ctx))
+
+    def profile_enable(self, on: bool):
+        self._ck(self._lib.swr_profile_enable(self._ctx, 1 if on else 0))
+
+    def profile(self) -> dict:
+        p = N.Profile()
+        self._ck(self._lib.swr_profile_get(self._ctx, C.byref(p)))
+        return {n: (float(getattr(p, n)) if t is C.c_double else int(getattr(p, n))) for n, t in N.Profile._fields_}
+
+    def profile_reset(self):
+        self._ck(self._lib.swr_profile_reset(self._ctx))
+
+    def set_stream(self, hip_stream: int):
+        self._ck(self._lib.swr_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    def flush(self):
+        self._ck(self._lib.swr_flush(self._ctx))
+
+    def sync(self):
+        self._ck(self._lib.swr_sync(self._ctx))
+
+
+class Texture:
+    """Texture(Image<Rgba32>), Texture.cs:31-68: RGBA8 pixels, nearest sampling with wrap."""
+
+    def __init__(self, device: Device, pixels_rgba8: np.ndarray):
+        px = np.ascontiguousarray(pixels_rgba8, dtype=np.uint8)
+        if px.ndim != 3 or px.shape[2] != 4:
+            raise ValueError("pixels must be (height, width, 4) uint8")
+        self._dev = device
+        self.Height, self.Width = int(px.shape[0]), int(px.shape[1])
+        self._h = C.c_void_p()
+        device._ck(device._lib.swr_texture_create(device._ctx, px.ctypes.data, self.Width, self.Height, C.byref(self._h)))
+
+    def Sample(self, uv) -> np.ndarray:
+        """Texture.Sample, Texture.cs:43-63 (batched: uv of shape (..., 2) -> (..., 4)); runs on the GPU."""
+        a = np.ascontiguousarray(np.asarray(uv, dtype=np.float32))
+        flat = a.reshape(-1, 2)
+        out = np.empty((flat.shape[0], 4), dtype=np.float32)
+        self._dev._ck(self._dev._lib.swr_texture_sample(self._dev._ctx, self._h, flat.ctypes.data, flat.shape[0], out.ctypes.data))
+        return out.reshape(a.shape[:-1] + (4,))
+
+    def Dispose(self):
+        if self._h:
+            self._dev._ck(self._dev._lib.swr_texture_destroy(self._dev._ctx, self._h))
+            self._h = C.c_void_p()
+
+
+class VertexShader:
+    def __init__(self, program: "ShaderProgram"):
+        self.program = program
+
+
+class FragmentShader:
+    def __init__(self, program: "ShaderProgram"):
+        self.program = program
+
+
+class ShaderProgram:
+    """Stands in for the reference's (VertexShader, FragmentShader) delegate pair (Shaders.cs:97-98)."""
+
+    def __init__(self, program: Program, uniforms: Optional[N.Uniforms] = None, texture: Optional[Texture] = None):
+        self.program = Program(program)
+        self.uniforms = uniforms if uniforms is not None else default_uniforms()
+        self.texture = texture
+        self.VertexShader = VertexShader(self)
+        self.FragmentShader = FragmentShader(self)
+
+
+class Shaders:
+    VertexInput = VERTEX_DTYPE      # Shaders.cs:10-24
+    Program = Program
+
+    @staticmethod
+    def FlatColor():
+        return ShaderProgram(Program.FlatColor)
+
+    @staticmethod
+    def Gouraud():
+        return ShaderProgram(Program.Gouraud)
+
+    @staticmethod
+    def Dust2LambertFog(uniforms=None, texture=None):     # Renderer.cs:830-860
+        return ShaderProgram(Program.Dust2LambertFog, uniforms, texture)
+
+    @staticmethod
+    def Phong4Point(uniforms, texture=None):
+        return ShaderProgram(Program.Phong4Point, uniforms, texture)
+
+
+class MainWindow:
+    """Framebuffer part of MainWindow (MainWindow.cs:25-31,378-436); buffers live in HBM."""
+
+    def __init__(self, device: Device, render_width: int = 800, render_height: int = 600):
+        self._dev = device
+        self.RenderWidth = 0
+        self.RenderHeight = 0
+        self._band = None
+        self.Resize(render_width, render_height)
+
+    def Resize(self, width: int, height: int):          # HandleResize, MainWindow.cs:320-321
+        self._dev._ck(self._dev._lib.swr_resize(self._dev._ctx, int(width), int(height)))
+        self.RenderWidth, self.RenderHeight = int(width), int(height)
+
+    def SetBand(self, first_tile_row: int, n_tile_rows: int):
+        self._dev._ck(self._dev._lib.swr_set_band(self._dev._ctx, int(first_tile_row), int(n_tile_rows)))
+        self._band = (int(first_tile_row), int(n_tile_rows))
+
+    def band_pixel_rows(self):
+        tiles_y = (self.RenderHeight + 15) // 16
+        if self._band is None:
+            return 0, max(self.RenderHeight, 0)
+        t0 = min(max(self._band[0], 0), tiles_y)
+        t1 = min(t0 + max(self._band[1], 0), tiles_y)
+        y0, y1 = t0 * 16, min(self.RenderHeight, t1 * 16)
+        return y0, max(0, y1 - y0)
+
+    def BindFramebuffer(self, color_ptr: int, depth_ptr: int):
+        self._dev._ck(self._dev._lib.swr_bind_framebuffer(self._dev._ctx, C.c_void_p(color_ptr), C.c_void_p(depth_ptr)))
+
+    def ClearColorBuffer(self, clear_color):             # MainWindow.cs:400-407
+        c = _f32(clear_color, 4)
+        self._dev._ck(self._dev._lib.swr_clear_color(self._dev._ctx, _fptr(c)))
+
+    def ClearDepthBuffer(self):                          # MainWindow.cs:429-436
+        self._dev._ck(self._dev._lib.swr_clear_depth(self._dev._ctx))
+
+    def _read(self, want_color=True, want_depth=True):
+        _, rows = self.band_pixel_rows()
+        w = max(self.RenderWidth, 0)
+        col = np.empty((rows, w, 4), dtype=np.float32) if want_color else None
+        dep = np.empty((rows, w), dtype=np.float32) if want_depth else None
+        self._dev._ck(self._dev._lib.swr_readback(self._dev._ctx, col.ctypes.data if want_color else None,
+                                                  dep.ctypes.data if want_depth else None))
+        return col, dep
+
+    @property
+    def ColorBuffer(self) -> np.ndarray:                 # Vector4[W*H], idx = y*W + x
+        return self._read(True, False)[0]
+
+    @property
+    def DepthBuffer(self) -> np.ndarray:
+        return self._read(False, True)[1]
+
+    def Upload(self, color=None, depth=None):
+        c = np.ascontiguousarray(color, dtype=np.float32) if color is not None else None
+        d = np.ascontiguousarray(depth, dtype=np.float32) if depth is not None else None
+        self._dev._ck(self._dev._lib.swr_upload(self._dev._ctx, c.ctypes.data if c is not None else None,
+                                                d.ctypes.data if d is not None else None))
+
+    def GetPixel(self, x: int, y: int) -> np.ndarray:    # MainWindow.cs:391-398
+        out = np.zeros(4, dtype=np.float32)
+        self._dev._ck(self._dev._lib.swr_get_pixel(self._dev._ctx, int(x), int(y), _fptr(out)))
+        return out
+
+    def SetPixel(self, x: int, y: int, color):           # MainWindow.cs:382-388
+        c = _f32(color, 4)
+        self._dev._ck(self._dev._lib.swr_set_pixel(self._dev._ctx, int(x), int(y), _fptr(c)))
+
+    def GetDepth(self, x: int, y: int) -> float:         # MainWindow.cs:420-426
+        out = C.c_float(0.0)
+        self._dev._ck(self._dev._lib.swr_get_depth(self._dev._ctx, int(x), int(y), C.byref(out)))
+        return float(np.float32(out.value))
+
+    def SetDepth(self, x: int, y: int, depth: float):    # MainWindow.cs:411-417
+        self._dev._ck(self._dev._lib.swr_set_depth(self._dev._ctx, int(x), int(y), float(depth)))
+
+
+class Mesh:
+    """Retained mesh: Mesh.Vertices / Mesh.Indices (ModelLoader.cs:45-47) uploaded once."""
+
+    def __init__(self, device: Device, vertices: np.ndarray, indices: np.ndarray):
+        v = as_vertex_array(vertices)
+        i = np.ascontiguousarray(indices, dtype=np.uint16).reshape(-1)
+        self._dev = device
+        self.n_vertices, self.n_indices = int(v.shape[0]), int(i.shape[0])
+        self._h = C.c_void_p()
+        device._ck(device._lib.swr_mesh_create(device._ctx, v.ctypes.data, self.n_vertices, i.ctypes.data, self.n_indices, C.byref(self._h)))
+
+    def Dispose(self):
+        if self._h:
+            self._dev._ck(self._dev._lib.swr_mesh_destroy(self._dev._ctx, self._h))
+            self._h = C.c_void_p()
+
+
+def as_vertex_array(vertices) -> np.ndarray:
+    v = np.asarray(vertices)
+    if v.dtype == VERTEX_DTYPE:
+        return np.ascontiguousarray(v).reshape(-1)
+    v = np.ascontiguousarray(v, dtype=np.float32)
+    if v.ndim != 2 or v.shape[1] != 12:
+        raise ValueError("vertices must have dtype VERTEX_DTYPE or shape (n, 12) float32")
+    return v.view(VERTEX_DTYPE).reshape(-1)
+
+
+class Rasterizer:
+    """public static class Rasterizer (Rasterizer.cs:12): statics + enums + RenderMesh."""
+
+    DebugMode = DebugMode
+    BlendMode = BlendMode
+    DepthTest = DepthTest
+    CullMode = CullMode
+
+    NearClip = 0.1                       # Rasterizer.cs:20
+    FarClip = 1000.0                     # Rasterizer.cs:21
+    RenderDebugMode = DebugMode.None_    # Rasterizer.cs:22
+
+    @staticmethod
+    def InitializeTileLocks(window: MainWindow, width: int, height: int):
+        """Rasterizer.cs:69-93; non-positive sizes raise (C#: ArgumentException)."""
+        try:
+            window._dev._ck(window._dev._lib.swr_initialize_tile_locks(window._dev._ctx, int(width), int(height)))
+        except N.SwrError as e:
+            if e.code == N.SWR_ERR_INVALID_ARG:
+                raise ValueError("Width and height must be positive non-zero values.") from e
+            raise
+
+    @classmethod
+    def RenderMesh(cls, window: MainWindow, vertices, indices, model, view, projection,
+                   vertexShader: VertexShader, fragmentShader: FragmentShader,
+                   cullMode: CullMode = CullMode.Back, depthTest: DepthTest = DepthTest.LessEqual,
+                   blendMode: BlendMode = BlendMode.Alpha):
+        """Rasterizer.RenderMesh, Rasterizer.cs:163-174.  `vertices` may be a retained `Mesh`
+        (then `indices` is ignored) or the VertexInput[] / ushort[] arrays of the C# signature."""
+        prog = fragmentShader.program
+        if vertexShader.program is not prog:
+            raise ValueError("vertexShader and fragmentShader must come from the same ShaderProgram")
+        dev = window._dev
+        dev._ck(dev._lib.swr_set_state(dev._ctx, float(cls.NearClip), float(cls.FarClip), int(cls.RenderDebugMode)))
+        m, v, p = _f32(model, 16), _f32(view, 16), _f32(projection, 16)
+        tex = prog.texture._h if prog.texture is not None else None
+        if isinstance(vertices, Mesh):
+            rc = dev._lib.swr_render_mesh(dev._ctx, vertices._h, _fptr(m), _fptr(v), _fptr(p), int(prog.program),
+                                          C.byref(prog.uniforms), tex, int(cullMode), int(depthTest), int(blendMode))
+        else:
+            va = as_vertex_array(vertices)
+            ia = np.ascontiguousarray(indices, dtype=np.uint16).reshape(-1)
+            rc = dev._lib.swr_render_mesh_arrays(dev._ctx, va.ctypes.data, int(va.shape[0]), ia.ctypes.data, int(ia.shape[0]),
+                                                 _fptr(m), _fptr(v), _fptr(p), int(prog.program), C.byref(prog.uniforms), tex,
+                                                 int(cullMode), int(depthTest), int(blendMode))
+        if rc == N.SWR_ERR_INVALID_ARG:
+            msg = dev._lib.swr_last_error(dev._ctx).decode()
+            if "index out of range" in msg:
+                raise IndexError(msg)      # C#: IndexOutOfRangeException
+        dev._ck(rc)
+
+    @staticmethod
+    def Interpolate(window: MainWindow, a, b, c, w, interpolate: bool = True) -> np.ndarray:
+        """Rasterizer.Interpolate (public, Rasterizer.cs:566-640), batched over n weight triples.
+        a, b, c: 20-float vertex records {clip4,color4,uv2,normal3,screen2,worldNormal3,pad2};
+        returns (n, 24): {clip4,color4,uv2,normal3,screen2,worldNormal3,bary3,pad3}."""
+        verts = np.concatenate([_f32(a, 20), _f32(b, 20), _f32(c, 20)])
+        wts = np.ascontiguousarray(np.asarray(w, dtype=np.float32).reshape(-1, 3))
+        out = np.empty((wts.shape[0], 24), dtype=np.float32)
+        dev = window._dev
+        dev._ck(dev._lib.swr_interpolate(dev._ctx, verts.ctypes.data, wts.ctypes.data, wts.shape[0], 1 if interpolate else 0, out.ctypes.data))
+        return out
