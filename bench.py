@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the raster hot path on MI355X.
+
+A "step" is one frame of the hot path over one batch of synthetic input: ClearDepth + ClearColor +
+one Rasterizer.RenderMesh per mesh (vertex transform, near clip, setup, 16x16-tile edge-function
+rasterisation, depth test, nearest-texture Lambert+fog shading, blend, framebuffer write), flushed
+and completed on the GPU.  Meshes and the texture are resident in HBM before the timed region.
+
+Workload at N=1 (BASELINE.json configs[2], the configuration the metric is quoted on):
+4096x4096, 1M triangles in 16 u16-indexed meshes, one 2048^2 RGBA8 texture, program
+DUST2_LAMBERT_FOG (= Renderer.cs:830-860), CullMode.Back, DepthTest.LessEqual, BlendMode.Alpha.
+At N>1 the same frame is sharded by tile rows (one band per rank, no collective while rendering)
+and the colour bands are gathered to rank 0 over RCCL each step: strong scaling.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_MEASURED_GBS = 6290.0
+BYTES_PER_WRITTEN_FRAGMENT = 20  # 16 B float4 colour + 4 B float depth
+
+
+def build_scene(name, args):
+    from softwarerenderer_amd import scenes
+    if name == "cfg3":
+        return scenes.cfg3()
+    if name == "cfg4":
+        return scenes.cfg4()
+    if name == "cfg5":
+        return scenes.cfg5()
+    if name == "cfg2":
+        return scenes.cfg2()
+    if name == "cfg3_small":      # quick functional check of the bench itself
+        return scenes.cfg3(1024, 1024, (4, 4), (64, 32), tex_size=512)
+    raise SystemExit(f"unknown config {name}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true", help="do not record hipEvents around kernels in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch                      # plumbing: device memory for the bands, streams, RCCL
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import numpy as np
+    from softwarerenderer_amd import Device, MainWindow, multigpu, scenes
+
+    scene = build_scene(args.config, args)
+    W, H = scene.width, scene.height
+    dev = Device(local_rank)
+    window = MainWindow(dev, W, H)
+    color_t = depth_t = None
+    if world > 1:
+        band = multigpu.band_partition(H, world)[rank]
+        rows = multigpu.max_band_rows(H, world)
+        color_t = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
+        depth_t = torch.zeros((rows, W), dtype=torch.float32, device="cuda")
+        window.SetBand(*band)
+        window.BindFramebuffer(color_t.data_ptr(), depth_t.data_ptr())
+        dev.set_stream(torch.cuda.current_stream().cuda_stream)   # order the gather after the frame
+    renderer = scenes.SceneRenderer(dev, scene, window=window)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        dev.sync()
+        torch.cuda.synchronize()
+
+    def step():
+        renderer.submit_frame()
+        dev.flush()
+        if world > 1:
+            multigpu.gather_bands(color_t, H, W, rank, world, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.reset_stats()
+    if not args.no_profile_events:
+        dev.profile_reset()
+        dev.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profile() if not args.no_profile_events else None
+    if not args.no_profile_events:
+        dev.profile_enable(False)
+    st = dev.stats()
+
+    # whole-job numbers: max time over ranks, fragments summed over ranks
+    counts = torch.tensor([st["fragments_tested"], st["fragments_written"], st["tile_pairs"]], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    frags_tested = counts[0].item() / args.steps
+    frags_written = counts[1].item() / args.steps
+    n_tris = scene.n_triangles
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        out = {
+            "metric": "Mfragments/s (depth-tested + textured fragments, whole frame)",
+            "value": round(frags_tested / (ms_per_step * 1e-3) / 1e6, 3),
+            "unit": "Mfragments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H}, {n_tris} triangles in {len(scene.draws)} u16 meshes, "
+                                   f"{'2048^2 RGBA8 nearest texture, ' if scene.textures else ''}"
+                                   f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
+                                   f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
+                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL colour gather to rank 0"},
+            "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
+            "fragments_tested_per_frame": int(frags_tested),
+            "fragments_written_per_frame": int(frags_written),
+            "tile_pairs_per_frame": int(counts[2].item() / args.steps),
+            "device": dev.name,
+        }
+        if prof is not None and prof["raster_launches"] > 0:
+            # dominant kernel = k_raster; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1)
+            raster_ms = prof["raster_ms"] / prof["raster_launches"]
+            written_local = st["fragments_written"] / args.steps
+            achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
+            frame_bytes = (W * H if world == 1 else color_t.shape[0] * W) * 20.0
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_raster",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 5),
+                "traffic": None,
+                "kernel_ms": round(raster_ms, 4),
+                "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "stage_ms_per_step": {k: round(prof[k] / args.steps, 4) for k in
+                                      ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "raster_ms", "clear_ms", "total_ms")},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, renderer, np)
+        print(json.dumps(out), flush=True)
+
+    renderer.close()
+    dev.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, renderer, np):
+    """The C restatement of the reference (oracle/, kind "port") timed on this box's host cores on the
+    SAME frame: all-core threaded variant (per-tile locks like Rasterizer.cs:478) for `value`, plus one
+    serial frame that is also compared word for word with the GPU frame."""
+    from oracle.binding import OracleRenderer
+    cores = os.cpu_count() or 1
+    o = OracleRenderer(scene.width, scene.height, threads=cores)
+    o.render_scene(scene)                      # warm-up
+    times = []
+    budget_t0 = time.perf_counter()
+    for _ in range(3):
+        o.reset_stats()
+        t0 = time.perf_counter()
+        o.render_scene(scene)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - budget_t0 > 20.0:
+            break
+    st = o.stats()
+    o.close()
+    t = sorted(times)[len(times) // 2]
+    res = {"value": round(st["fragments_tested"] / t / 1e6, 3), "unit": "Mfragments/s", "cores": cores, "kind": "port",
+           "sample": f"the whole {scene.name} frame, median of {len(times)} frames after 1 warm-up, "
+                     f"threaded C restatement of Rasterizer.cs (oracle/swr_oracle.c)",
+           "ms_per_frame": round(t * 1e3, 2)}
+    # one serial frame = the oracle of record; doubles as a full-size parity check of the GPU frame
+    o = OracleRenderer(scene.width, scene.height, threads=1)
+    t0 = time.perf_counter()
+    rc, rd = o.render_scene(scene)
+    ts = time.perf_counter() - t0
+    sst = o.stats()
+    o.close()
+    res["serial_value"] = round(sst["fragments_tested"] / ts / 1e6, 3)
+    gc, gd = renderer.render()
+    depth_exact = bool(np.array_equal(gd.view(np.uint32), rd.view(np.uint32)))
+    a = gc.view(np.int32).astype(np.int64); b = rc.view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a); b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    res["gpu_frame_matches_serial_port"] = {"depth_bit_exact": depth_exact, "color_max_ulp": int(np.abs(a - b).max())}
+    return res
+
+
+if __name__ == "__main__":
+    main()

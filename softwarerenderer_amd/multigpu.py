@@ -1,0 +1,79 @@
+"""Multi-GPU frames: contiguous bands of 16-pixel tile rows, one process per GPU, colour gather.
+
+The reference already parallelises a triangle over tile rows (Rasterizer.cs:462); pixels are
+independent given the ordered triangle list, so a frame shards by screen-space tile rows with NO
+data-path collective while rendering: every rank holds the (small) geometry, runs vertex + setup
+for all triangles and bins / rasterises only the tiles of its band -- a triangle straddling a band
+edge is rasterised on both sides with identical per-tile arithmetic, so the union of the bands is
+bit-identical to the single-GPU frame.  The one exchange step is the end-of-frame gather of the
+colour bands to rank 0 (RCCL send/recv over xGMI: 7 links into the root concurrently; a ring
+all-gather would be per-link bound).
+
+torch / torch.distributed are plumbing here (device memory for the bands, streams, RCCL).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+TILE = 16
+
+
+def tile_rows(height: int) -> int:
+    return (max(height, 0) + TILE - 1) // TILE
+
+
+def band_partition(height: int, world_size: int) -> List[Tuple[int, int]]:
+    """Split the frame's tile rows into `world_size` contiguous bands (first_tile_row, n_tile_rows),
+    sizes differing by at most one row; ranks beyond the number of tile rows get empty bands."""
+    n = tile_rows(height)
+    q, r = divmod(n, world_size)
+    out, start = [], 0
+    for i in range(world_size):
+        cnt = q + (1 if i < r else 0)
+        out.append((start, cnt))
+        start += cnt
+    return out
+
+
+def band_pixel_rows(height: int, band: Tuple[int, int]) -> Tuple[int, int]:
+    """(first pixel row, number of pixel rows) stored by a band."""
+    y0 = band[0] * TILE
+    y1 = min(height, (band[0] + band[1]) * TILE)
+    return y0, max(0, y1 - y0)
+
+
+def max_band_rows(height: int, world_size: int) -> int:
+    return max(band_pixel_rows(height, b)[1] for b in band_partition(height, world_size))
+
+
+def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None):
+    """Gather the per-rank colour bands (torch tensors of shape (max_band_rows, width, C), rows beyond a
+    band's own count are padding) to `dst`; returns the assembled (height, width, C) frame there, else None.
+    Works on any backend (nccl == RCCL on ROCm; gloo on CPU for the tests)."""
+    import torch
+    import torch.distributed as dist
+    if world_size == 1:
+        return local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
+    bufs = None
+    if rank == dst:
+        bufs = [torch.empty_like(local_band) for _ in range(world_size)]
+    dist.gather(local_band, gather_list=bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    frame = torch.empty((height, width) + tuple(local_band.shape[2:]), dtype=local_band.dtype, device=local_band.device)
+    for r, band in enumerate(band_partition(height, world_size)):
+        y0, rows = band_pixel_rows(height, band)
+        if rows:
+            frame[y0:y0 + rows] = bufs[r][:rows]
+    return frame
+
+
+def assemble_numpy(bands: List[np.ndarray], height: int, world_size: int) -> np.ndarray:
+    """Host-side equivalent of gather_bands for arrays already on one process (tests)."""
+    parts = []
+    for r, band in enumerate(band_partition(height, world_size)):
+        _, rows = band_pixel_rows(height, band)
+        parts.append(bands[r][:rows])
+    return np.concatenate(parts, axis=0)
