@@ -1,0 +1,67 @@
+"""Host-side logic: enum ordinals, scene generators, matrix factories, band partition."""
+import numpy as np
+import pytest
+
+from softwarerenderer_amd import hostmath as hm, multigpu, scenes
+from softwarerenderer_amd.rasterizer import (BlendMode, CullMode, DebugMode, DepthTest, Rasterizer, VERTEX_DTYPE,
+                                              as_vertex_array, default_uniforms)
+
+
+def test_enum_ordinals_match_the_reference():
+    assert [int(x) for x in DebugMode] == [0, 1]                       # Rasterizer.cs:14-18
+    assert [x.name for x in BlendMode] == ["None_", "Alpha", "Additive", "Multiply"]      # :25-31
+    assert [x.name for x in DepthTest] == ["Disabled", "Less", "LessEqual", "Greater", "GreaterEqual", "Equal", "NotEqual", "Always"]
+    assert [x.name for x in CullMode] == ["None_", "Back", "Front"]    # :45-50
+    assert Rasterizer.NearClip == 0.1 and Rasterizer.FarClip == 1000.0  # :20-21
+
+
+def test_default_uniforms_are_the_reference_defaults():
+    u = default_uniforms()                                             # Renderer.cs:39-44
+    assert (u.fog_start, u.fog_end) == (1.0, 25.0)
+    assert np.allclose(list(u.fog_color), [1.0, 0.62, 0.5, 1.0])
+    assert np.allclose(list(u.light_direction), [0.5, -np.sqrt(0.5), -0.5], atol=1e-6)   # EulerToDirection(-45,-45,0)
+
+
+def test_vertex_array_views():
+    v = np.zeros((5, 12), dtype=np.float32)
+    assert as_vertex_array(v).dtype == VERTEX_DTYPE and as_vertex_array(v).shape == (5,)
+    with pytest.raises(ValueError):
+        as_vertex_array(np.zeros((5, 11), dtype=np.float32))
+
+
+def test_scenes_are_deterministic_and_fit_u16():
+    a, b = scenes.cfg2(320, 200, 500), scenes.cfg2(320, 200, 500)
+    assert a.draws[0].vertices.tobytes() == b.draws[0].vertices.tobytes()
+    s = scenes.cfg3(256, 256, (2, 2), (16, 8), tex_size=32)
+    assert s.n_triangles == 2 * 2 * 16 * 8 * 2
+    for d in s.draws:
+        assert d.vertices.shape[0] <= 65535 and d.indices.dtype == np.uint16 and int(d.indices.max()) < d.vertices.shape[0]
+
+
+def test_full_size_cfg3_shape():
+    s = scenes.cfg3()
+    assert (s.width, s.height, s.n_triangles, len(s.draws)) == (4096, 4096, 1_000_000, 16)
+    assert s.textures[0].shape == (2048, 2048, 4) and int(s.textures[0][..., 3].min()) == 255
+
+
+def test_perspective_matches_system_numerics_layout():
+    p = hm.create_perspective_fov(np.pi / 2, 2.0, 0.1, 1000.0)
+    assert p[2, 3] == -1.0 and p[3, 3] == 0.0
+    assert np.isclose(p[0, 0], 0.5) and np.isclose(p[1, 1], 1.0)
+    assert np.isclose(p[2, 2], 1000.0 / (0.1 - 1000.0)) and np.isclose(p[3, 2], 0.1 * 1000.0 / (0.1 - 1000.0))
+    v = hm.create_look_at((0, 0, 0), (0, 0, -1), (0, 1, 0))
+    assert np.allclose(v, np.eye(4))
+
+
+@pytest.mark.parametrize("height,world", [(4096, 8), (8192, 8), (1080, 4), (100, 8), (16, 4), (1, 2), (333, 3)])
+def test_band_partition_covers_every_tile_row_once(height, world):
+    bands = multigpu.band_partition(height, world)
+    assert len(bands) == world
+    rows = sum(n for _, n in bands)
+    assert rows == multigpu.tile_rows(height)
+    nxt = 0
+    for first, n in bands:
+        assert first == nxt
+        nxt += n
+    assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
+    assert sum(multigpu.band_pixel_rows(height, b)[1] for b in bands) == height

@@ -1,0 +1,215 @@
+"""Known-answer tests that pin the CPU oracle WITHOUT the reference (which ships no tests or vectors and
+cannot be built here: SURVEY.md section 8c).  Every expected value below is derived by hand / exact
+arithmetic from the reference's formulas (file:line cited), not produced by the oracle itself."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from softwarerenderer_amd import hostmath as hm, scenes
+from softwarerenderer_amd.rasterizer import BlendMode, CullMode, DepthTest, Program
+
+MINVAL = np.float32(-3.4028235e38)      # float.MinValue, MainWindow.cs:434
+
+
+def cfg1_mask():
+    """Analytic coverage of cfg1: screen vertices (64,192),(192,192),(128,64) (Rasterizer.cs:383-386), all
+    arithmetic exact in float32; a pixel (integer sample point, no +0.5, no top-left rule: :493-494) is covered
+    iff 64 <= y <= 192 and 2*|x-128| <= y-64."""
+    y, x = np.mgrid[0:256, 0:256]
+    return (y >= 64) & (y <= 192) & (2 * np.abs(x - 128) <= (y - 64))
+
+
+def test_cfg1_coverage_colour_and_untouched_depth(oracle_lib):
+    s = scenes.cfg1()
+    o = ob.OracleRenderer(s.width, s.height)
+    color, depth = o.render_scene(s)
+    mask = cfg1_mask()
+    assert mask.sum() == 8321            # sum_{k=0..128} (2*floor(k/2)+1)
+    # flat (Interpolate=false): attributes come from outputs[0] = original v2 (Rasterizer.cs:367,622-627) = blue
+    assert np.array_equal(color[mask], np.tile(np.float32([0, 0, 1, 1]), (8321, 1)))
+    assert np.array_equal(color[~mask], np.tile(np.float32([0, 0, 0, 1]), ((~mask).sum(), 1)))
+    # DepthTest.Disabled never writes Z (Rasterizer.cs:517-518): still the clear value
+    assert np.all(depth == MINVAL)
+    st = o.stats()
+    assert st["fragments_tested"] == st["fragments_written"] == 8321 and st["triangles_setup"] == 1
+
+
+def test_blend_none_early_out_breaks_the_row_within_a_tile(oracle_lib):
+    """canEarlyOut (Rasterizer.cs:520-523): alpha 0 + BlendMode.None -> the first covered pixel of each row of
+    each 16x16 tile is shaded, fails `W > 0`, and ends that row segment.  Nothing is written."""
+    s = scenes.cfg1()
+    s.draws[0].vertices["color"][:, 3] = 0.0
+    s.draws[0].blend = BlendMode.None_
+    o = ob.OracleRenderer(s.width, s.height)
+    color, _ = o.render_scene(s)
+    assert np.array_equal(color, np.tile(np.float32([0, 0, 0, 1]), (256, 256, 1)))
+    mask = cfg1_mask()
+    segments = sum(int(mask[y, tx * 16:(tx + 1) * 16].any()) for y in range(256) for tx in range(16))
+    st = o.stats()
+    assert st["fragments_shaded"] == segments and st["fragments_written"] == 0
+
+
+def test_depth_function_names_are_inverted_as_written(oracle_lib):
+    f = oracle_lib.oswr_depth_func
+    # GetDepthTestFunction, Rasterizer.cs:543-559: LessEqual -> new >= old, Less -> new > old, ...
+    assert f(DepthTest.LessEqual, 0.5, 0.25) == 1 and f(DepthTest.LessEqual, 0.25, 0.5) == 0 and f(DepthTest.LessEqual, 0.5, 0.5) == 1
+    assert f(DepthTest.Less, 0.5, 0.5) == 0 and f(DepthTest.Less, 0.75, 0.5) == 1
+    assert f(DepthTest.Greater, 0.25, 0.5) == 1 and f(DepthTest.Greater, 0.5, 0.5) == 0
+    assert f(DepthTest.GreaterEqual, 0.5, 0.5) == 1 and f(DepthTest.GreaterEqual, 0.75, 0.5) == 0
+    assert f(DepthTest.Equal, 0.5, 0.5 + 5e-7) == 1 and f(DepthTest.Equal, 0.5, 0.5 + 2e-6) == 0
+    assert f(DepthTest.NotEqual, 0.5, 0.5 + 2e-6) == 1 and f(DepthTest.NotEqual, 0.5, 0.5) == 0
+    assert f(DepthTest.Disabled, 0.0, 1.0) == 1 and f(DepthTest.Always, 0.0, 1.0) == 1
+    assert f(DepthTest.LessEqual, 0.0, float(MINVAL)) == 1       # everything beats the cleared buffer
+
+
+def test_nearer_fragment_wins_and_ties_go_to_the_later_triangle(oracle_lib):
+    """Hand derivation (corrects SURVEY.md fact 1).  With s0=(0,0), s1=(1,0), s2=(0,1):
+    area = EdgeFunction(s0,s1,s2) = -1 (Rasterizer.cs:411,562) while w0 at p=s0 is
+    a12*(0-s1.x) + b12*(0-s1.y) = (-1)(-1) + 0 = +1 (Rasterizer.cs:445-447,481): each edge weight at its own
+    vertex is -area, so w0f+w1f+w2f = -1 and the stored depth is MINUS the interpolated (ndc.z+1)/2.
+    (ndc.z+1)/2 grows with distance, its negation shrinks, and LessEqual is `new >= old` (:545-546):
+    the NEARER fragment wins; equal depths -> the later triangle overwrites (>=)."""
+    proj = hm.create_perspective_fov(np.pi / 2, 1.0, 0.1, 1000.0)
+    I = hm.identity()
+
+    def tri(z, rgb):
+        p = [(-4 * z, -4 * z, -z), (4 * z, -4 * z, -z), (0, 4 * z, -z)]
+        return scenes.make_vertices(p, color=[rgb + (1.0,)] * 3)
+
+    def render(order):
+        v = np.concatenate([tri(z, rgb) for z, rgb in order])
+        d = scenes.Draw(v, np.arange(len(v), dtype=np.uint16), I, I, proj, program=Program.Gouraud, cull=CullMode.None_)
+        o = ob.OracleRenderer(32, 32)
+        c, dz = o.render_scene(scenes.Scene("t", 32, 32, [d]))
+        return tuple(c[16, 16, :3]), float(dz[16, 16])
+
+    near, far = (2.0, (1.0, 0.0, 0.0)), (5.0, (0.0, 1.0, 0.0))
+    for order in ([near, far], [far, near]):
+        rgb, z = render(order)
+        assert rgb == (1.0, 0.0, 0.0)                      # near (red) wins in either order
+        # ndc.z at z_view=-2: (2*1.0001 - 0.10001)/2 = 0.95005 -> (ndc.z+1)/2 = 0.975025 ; stored NEGATED
+        assert abs(z + 0.975025) < 1e-4
+    same_a, same_b = (3.0, (1.0, 0.0, 0.0)), (3.0, (0.0, 0.0, 1.0))
+    assert render([same_a, same_b])[0] == (0.0, 0.0, 1.0)  # tie: the later triangle overwrites
+    assert render([same_b, same_a])[0] == (1.0, 0.0, 0.0)
+
+
+def test_blend_formulas(oracle_lib):
+    def blend(src, dst, mode):
+        s, d, o = np.float32(src), np.float32(dst), np.zeros(4, np.float32)
+        oracle_lib.oswr_blend(s.ctypes.data, d.ctypes.data, int(mode), o.ctypes.data)
+        return tuple(o)
+    src, dst = (0.5, 0.25, 1.0, 0.5), (1.0, 1.0, 0.0, 1.0)
+    assert blend(src, dst, BlendMode.None_) == src
+    assert blend(src, dst, BlendMode.Alpha) == (0.75, 0.625, 0.5, 0.75)      # src*a + dst*(1-a) on all four channels
+    assert blend(src, dst, BlendMode.Additive) == (1.0, 1.0, 1.0, 1.0)       # min(src+dst, 1)
+    assert blend((0.25, 0.25, 0.25, 0.25), (0.5, 0.5, 0.5, 0.5), BlendMode.Additive) == (0.75,) * 4
+    assert blend(src, dst, BlendMode.Multiply) == (0.5, 0.25, 0.0, 0.5)
+
+
+def test_texture_sample_nearest_wrap(oracle_lib):
+    tex = np.arange(2 * 2 * 4, dtype=np.uint8).reshape(2, 2, 4) * 10     # texel (x,y) = tex[y, x]
+    inv255 = np.float32(1.0) / np.float32(255.0)
+
+    def sample(u, v):
+        uv, out = np.float32([u, v]), np.zeros(4, np.float32)
+        oracle_lib.oswr_texture_sample(tex.ctypes.data, 2, 2, uv.ctypes.data, out.ctypes.data)
+        return out
+
+    def texel(x, y):
+        return tex[y, x].astype(np.float32) * inv255      # byte * (1f/255f), Texture.cs:57-62
+
+    assert np.array_equal(sample(0.25, 0.25), texel(0, 0))
+    assert np.array_equal(sample(0.75, 0.25), texel(1, 0))
+    assert np.array_equal(sample(0.25, 0.75), texel(0, 1))
+    assert np.array_equal(sample(-0.25, 0.25), texel(1, 0))   # u - (int)u = -0.25 -> +1 = 0.75
+    assert np.array_equal(sample(2.75, -1.75), texel(1, 0))   # wrap: 0.75, 0.25
+    assert np.array_equal(sample(1.0, 3.0), texel(0, 0))      # exact integers wrap to 0
+    assert np.array_equal(sample(-1e-9, 0.25), texel(0, 0))   # -1e-9 + 1 rounds to 1.0f -> (int)(2.0) % 2 = 0
+    # .NET 9 float->int conversions saturate (documented assumption): (int)1e20 = int.MaxValue, MaxValue % 2 = 1
+    assert np.array_equal(sample(1e20, 0.25), texel(1, 0))
+    assert np.array_equal(sample(float("nan"), 0.25), texel(0, 0))   # (int)NaN = 0
+
+
+def test_edge_function(oracle_lib):
+    def e(a, b, c):
+        a, b, c = np.float32(a), np.float32(b), np.float32(c)
+        return oracle_lib.oswr_edge_function(a.ctypes.data, b.ctypes.data, c.ctypes.data)
+    assert e((0, 0), (1, 0), (0, 1)) == -1.0      # (c.x-a.x)*(b.y-a.y) - (c.y-a.y)*(b.x-a.x), Rasterizer.cs:562-563
+    assert e((0, 0), (0, 1), (1, 0)) == 1.0
+    assert e((1, 1), (2, 2), (3, 3)) == 0.0
+
+
+def _vo(clip, color=(0, 0, 0, 0), uv=(0, 0), normal=(0, 0, 0), screen=(0, 0), wn=(0, 0, 1), interp=1):
+    v = ob.OVertexOutput()
+    v.clip[:] = clip; v.color[:] = color; v.texcoord[:] = uv; v.normal[:] = normal; v.screen[:] = screen
+    v.world_normal[:] = wn; v.has_data = 1; v.interpolate = interp
+    return v
+
+
+def test_interpolate_perspective_correct(oracle_lib):
+    """Rasterizer.Interpolate, Rasterizer.cs:566-640: r_i = w_i / W_i; attr = ((A*rA + B*rB) + C*rC) * (1 / sum r)."""
+    a = _vo((1, 2, 3, 1), color=(1, 0, 0, 1), uv=(0, 0), wn=(1, 0, 0))
+    b = _vo((4, 5, 6, 2), color=(0, 1, 0, 1), uv=(1, 0), wn=(0, 1, 0))
+    c = _vo((7, 8, 9, 4), color=(0, 0, 1, 0.5), uv=(0, 1), wn=(0, 0, 1))
+    out = ob.OVertexOutput()
+    oracle_lib.oswr_interpolate(C.byref(a), C.byref(b), C.byref(c), 0.5, 0.25, 0.25, 1, C.byref(out))
+    f = np.float32
+    ra, rb, rc = f(0.5) / f(1), f(0.25) / f(2), f(0.25) / f(4)        # 0.5, 0.125, 0.0625 (exact)
+    w = f(1.0) / ((ra + rb) + rc)
+    exp_clip = [((f(x) * ra + f(y) * rb) + f(z) * rc) * w for x, y, z in zip(a.clip, b.clip, c.clip)]
+    assert list(out.clip) == exp_clip
+    assert list(out.texcoord) == [((f(0) * ra + f(1) * rb) + f(0) * rc) * w, ((f(0) * ra + f(0) * rb) + f(1) * rc) * w]
+    assert out.color[3] == ((f(1) * ra + f(1) * rb) + f(0.5) * rc) * w
+    wa, wb, wc = ra * w, rb * w, rc * w
+    assert list(out.barycentric) == [wa, wb, wc]
+    n = np.array([wa, wb, wc], dtype=f)                                # Data: normalised weights, then renormalise (:680-688)
+    ln = (n[0] * n[0] + n[1] * n[1]) + n[2] * n[2]
+    s = f(1.0) / np.sqrt(ln)
+    assert list(out.world_normal) == [n[0] * s, n[1] * s, n[2] * s]
+    # flat (interpolate=false): Normal/Color/Data copied from a; position/uv still interpolated (:622-627)
+    oracle_lib.oswr_interpolate(C.byref(a), C.byref(b), C.byref(c), 0.5, 0.25, 0.25, 0, C.byref(out))
+    assert list(out.color) == [1, 0, 0, 1] and list(out.world_normal) == [1, 0, 0] and list(out.clip) == exp_clip
+
+
+def test_shaders_lerp(oracle_lib):
+    """Shaders.Lerp, Shaders.cs:50-95 with Vector.Lerp = a*(1-t) + b*t; WorldNormal is NOT renormalised."""
+    a = _vo((0, 0, 0, 1), color=(1, 1, 1, 1), uv=(0, 4), wn=(1, 0, 0))
+    b = _vo((8, 4, 2, 3), color=(0, 0.5, 1, 0), uv=(2, 0), wn=(0, 1, 0))
+    out = ob.OVertexOutput()
+    oracle_lib.oswr_lerp(C.byref(a), C.byref(b), 0.25, 1, C.byref(out))
+    assert list(out.clip) == [2.0, 1.0, 0.5, 1.5]
+    assert list(out.texcoord) == [0.5, 3.0]
+    assert list(out.color) == [0.75, 0.875, 1.0, 0.75]
+    assert list(out.world_normal) == [0.75, 0.25, 0.0]
+    assert out.interpolate == 1 and list(out.screen) == [0.0, 0.0]
+
+
+def test_vertex_shader_three_chained_transforms(oracle_lib):
+    """Renderer.VertexShader, Renderer.cs:830-846: clip = ((pos,1)*model)*view*proj, WorldNormal = Normalize(TransformNormal)."""
+    vin = scenes.make_vertices([(1.0, 2.0, 3.0)], uv=[(0.25, 0.75)], normal=[(0.0, 0.0, 2.0)], color=[(0.1, 0.2, 0.3, 0.4)])
+    model = hm.create_scale(2.0)
+    view = hm.create_translation(10.0, 20.0, 30.0)
+    proj = hm.identity(); proj[2, 3] = -1.0                       # w' = w - z
+    out = ob.OVertexOutput()
+    oracle_lib.oswr_vertex_shader(vin.ctypes.data, model.ctypes.data, view.ctypes.data, proj.ctypes.data,
+                                  int(Program.Dust2LambertFog), C.byref(out))
+    assert list(out.clip) == [12.0, 24.0, 36.0, 1.0 - 36.0]
+    assert list(out.world_normal) == [0.0, 0.0, 1.0]
+    assert list(out.texcoord) == [0.25, 0.75] and out.interpolate == 1
+    assert np.allclose(list(out.color), [0.1, 0.2, 0.3, 0.4], rtol=0, atol=0) or list(out.color) == list(vin["color"][0])
+
+
+def test_out_of_range_index_is_an_error(oracle_lib):
+    s = scenes.cfg1()
+    s.draws[0].indices = np.array([0, 1, 7], dtype=np.uint16)
+    o = ob.OracleRenderer(s.width, s.height)
+    with pytest.raises(IndexError):
+        o.render_scene(s)
+
+
+def test_fma_variant_is_a_different_build(oracle_lib):
+    assert oracle_lib.oswr_numerics_fma() == 0
+    assert ob.load(fma=True).oswr_numerics_fma() == 1

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output dirs (gpurun_out/...) into a small tracked summary under profiles/.
+
+usage: summarize_rocprof.py TAG STATS_DIR [PMC_FETCH_DIR] [PMC_WRITE_DIR] [BENCH_JSON]
+Writes profiles/TAG_kernel_stats.csv (verbatim rocprofv3 --stats table) and profiles/TAG_summary.md.
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in
+KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of a wide coalesced stream, so the read side is reported both
+raw and doubled (k_raster's reads are scalar record loads and 4-byte texel gathers -- uncalibrated widths --
+so the truth lies between the two); WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def pmc_means(d, counter):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                out[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    fetch_dir = sys.argv[3] if len(sys.argv) > 3 else None
+    write_dir = sys.argv[4] if len(sys.argv) > 4 else None
+    bench = sys.argv[5] if len(sys.argv) > 5 else None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    ks = glob.glob(os.path.join(stats_dir, "**", "*_kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(ks, os.path.join(prof, f"{tag}_kernel_stats.csv"))
+    rows = list(csv.DictReader(open(ks)))
+    fetch = pmc_means(fetch_dir, "FETCH_SIZE") if fetch_dir else {}
+    write = pmc_means(write_dir, "WRITE_SIZE") if write_dir else {}
+    lines = [f"# rocprofv3 summary `{tag}`", "",
+             "`rocprofv3 --kernel-trace --stats -- python3 bench.py ...` (kernel time) and separate `--pmc FETCH_SIZE` / "
+             "`--pmc WRITE_SIZE` passes (HBM-side traffic per launch, KiB -> MB).", "",
+             "| kernel | calls | avg us | % | FETCH MB raw (x2) | WRITE MB |", "|---|---|---|---|---|---|"]
+    for r in rows:
+        name = r["Name"].split("(")[0]
+        f = fetch.get(name); w = write.get(name)
+        lines.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
+                     f"{'' if f is None else f'{f * 1024 / 1e6:.1f} ({2 * f * 1024 / 1e6:.1f})'} | "
+                     f"{'' if w is None else f'{w * 1024 / 1e6:.1f}'} |")
+    if bench and os.path.exists(bench):
+        txt = open(bench).read().strip().splitlines()
+        js = [l for l in txt if l.startswith("{")]
+        if js:
+            lines += ["", "bench.py line of the same command:", "", "```json", json.dumps(json.loads(js[-1]), indent=1), "```"]
+    open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:20]))
+
+
+if __name__ == "__main__":
+    main()
