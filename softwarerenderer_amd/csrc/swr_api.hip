@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -18,6 +19,8 @@
 #include "swr_geometry.hip.h"
 #include "swr_binning.hip.h"
 #include "swr_raster.hip.h"
+#include "swr_raster_q.hip.h"
+#include "swr_raster_b.hip.h"
 
 using namespace swr;
 
@@ -85,6 +88,8 @@ struct swr_context {
     swr_stats totals = {};
 
     bool profiling = false;
+    bool force_immediate = false;             // SWR_RASTER=imm: always use k_raster (A/B and tests)
+    int raster_variant = 0;                   // SWR_RASTER=q: k_raster_q; default k_raster_b
     std::vector<EventSpan> spans;
     std::vector<hipEvent_t> event_pool;
     swr_profile prof = {};
@@ -220,7 +225,7 @@ int run_clear(swr_context* c) {
 }
 
 // bins slots [lo, hi) and rasterises them; splits the range when the pair list would not fit
-int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi) {
+int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
@@ -252,8 +257,8 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi) {
         // because the framebuffer carries the state from one round to the next.
         uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
         if (mid == lo) mid = lo + 2;
-        if ((rc = bin_and_raster(c, lo, mid))) return rc;
-        return bin_and_raster(c, mid, hi);
+        if ((rc = bin_and_raster(c, lo, mid, immediate))) return rc;
+        return bin_and_raster(c, mid, hi, immediate);
     }
     c->totals.tile_pairs += total;
     if (total == 0) return run_clear(c);
@@ -291,7 +296,10 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi) {
         ra.clear_depth_on = c->pend_clear_depth ? 1 : 0;
         ra.blocks_x = (c->tiles_x + 1) / 2;
         ra.blocks_y = (c->band_ty1 - c->band_ty0 + 1) / 2;
-        hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
+        if (immediate) hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        else hipLaunchKernelGGL(k_raster_b, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
         SWR_HIP(c, hipGetLastError());
         c->pend_clear_color = c->pend_clear_depth = false;
     }
@@ -364,7 +372,9 @@ int flush_locked(swr_context* c) {
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>());
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, 0, (uint32_t)(2 * T));
+    bool immediate = c->force_immediate;
+    for (auto& d : c->draws) immediate = immediate || d.p.blend == SWR_BLEND_NONE;
+    rc = bin_and_raster(c, 0, (uint32_t)(2 * T), immediate);
     for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
     c->draws.clear(); c->pend_verts = c->pend_tris = 0;
     c->totals.flushes++;
@@ -466,6 +476,7 @@ int swr_create(int device_id, swr_context** out) {
         g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
     }
     c->stream = c->own_stream;
+    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : 0; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_total, 64);
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
