@@ -168,7 +168,7 @@ def main():
                 "kernel_ms": round(raster_ms, 4),
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": {k: round(prof[k] / args.steps, 4) for k in
-                                      ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "raster_ms", "clear_ms", "total_ms")},
+                                      ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "cover_ms", "raster_ms", "clear_ms", "total_ms")},
             }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, renderer, np)

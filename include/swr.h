@@ -99,7 +99,7 @@ typedef struct swr_stats {            /* counters for the last flushed batch and
 
 /* per-stage GPU time of flushes since swr_profile_reset, from hipEvents on the context's stream */
 typedef struct swr_profile {
-    double vertex_ms, setup_ms, bin_ms, sort_ms, raster_ms, clear_ms, total_ms;
+    double vertex_ms, setup_ms, bin_ms, sort_ms, cover_ms, raster_ms, clear_ms, total_ms;
     uint64_t raster_launches, flushes;
 } swr_profile;
 
@@ -183,6 +183,8 @@ int  swr_profile_enable(swr_context* ctx, int on);       /* hipEvent pairs aroun
 int  swr_profile_get(swr_context* ctx, swr_profile* out); /* syncs */
 int  swr_profile_reset(swr_context* ctx);
 int  swr_device_name(swr_context* ctx, char* buf, int buflen);
+/* kernel-internal work counters; all zero unless the library was built with -DSWR_DEBUG_COUNTERS (tools/) */
+int  swr_debug_counters(swr_context* ctx, uint64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -54,7 +54,7 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [(n, C.c_double) for n in ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "raster_ms", "clear_ms", "total_ms")] + \
+    _fields_ = [(n, C.c_double) for n in ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "cover_ms", "raster_ms", "clear_ms", "total_ms")] + \
                [("raster_launches", C.c_uint64), ("flushes", C.c_uint64)]
 
 
@@ -66,7 +66,7 @@ EXPORTS = [
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
-    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name",
+    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def load() -> C.CDLL:
         "swr_profile_get": (I, [P, C.POINTER(Profile)]),
         "swr_profile_reset": (I, [P]),
         "swr_device_name": (I, [P, C.c_char_p, I]),
+        "swr_debug_counters": (I, [P, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

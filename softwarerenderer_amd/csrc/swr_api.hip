@@ -21,6 +21,7 @@
 #include "swr_raster.hip.h"
 #include "swr_raster_q.hip.h"
 #include "swr_raster_b.hip.h"
+#include "swr_raster_c.hip.h"
 
 using namespace swr;
 
@@ -45,7 +46,7 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Stage { ST_VERTEX = 0, ST_SETUP, ST_BIN, ST_SORT, ST_RASTER, ST_CLEAR, ST_COUNT };
+enum Stage { ST_VERTEX = 0, ST_SETUP, ST_BIN, ST_SORT, ST_COVER, ST_RASTER, ST_CLEAR, ST_COUNT };
 
 struct EventSpan { int stage; hipEvent_t a, b; };
 
@@ -83,13 +84,14 @@ struct swr_context {
     std::vector<swr_mesh*> garbage;           // transient meshes to free at the next sync point
 
     DevBuf d_draws, d_vblocks, d_tblocks, d_vout, d_recs, d_slot_tb;
+    DevBuf d_pair_tile, d_masks, d_pcounts;
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
 
     bool profiling = false;
     bool force_immediate = false;             // SWR_RASTER=imm: always use k_raster (A/B and tests)
-    int raster_variant = 0;                   // SWR_RASTER=q: k_raster_q; default k_raster_b
+    int raster_variant = 0;                   // SWR_RASTER=q: k_raster_q, b: k_raster_b; default k_cover + k_raster_c
     std::vector<EventSpan> spans;
     std::vector<hipEvent_t> event_pool;
     swr_profile prof = {};
@@ -184,6 +186,7 @@ void collect_spans(swr_context* c) {      // stream must be idle
             case ST_SETUP:  c->prof.setup_ms += ms; break;
             case ST_BIN:    c->prof.bin_ms += ms; break;
             case ST_SORT:   c->prof.sort_ms += ms; break;
+            case ST_COVER:  c->prof.cover_ms += ms; break;
             case ST_RASTER: c->prof.raster_ms += ms; c->prof.raster_launches++; break;
             case ST_CLEAR:  c->prof.clear_ms += ms; break;
             }
@@ -236,6 +239,7 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     ba.tile_count = c->d_tile_count.as<uint32_t>();
     ba.tile_start = c->d_tile_start.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
+    ba.pair_tile = c->d_pair_tile.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
     const uint32_t bin_blocks = (hi - lo + 255u) / 256u;
@@ -265,6 +269,13 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     if (total > 0xffffffffull) return fail(c, SWR_ERR_UNSUPPORTED, "a single triangle covers more tile pairs than one round can hold");
 
     if ((rc = ensure(c, c->d_tile_list, (size_t)total * 4))) return rc;
+    if ((rc = ensure(c, c->d_pair_tile, (size_t)total * 4))) return rc;
+    const bool use_cover = !immediate && c->raster_variant == 0;
+    if (use_cover) {
+        if ((rc = ensure(c, c->d_masks, (size_t)total * 32))) return rc;
+        if ((rc = ensure(c, c->d_pcounts, (size_t)total * 2 + 64))) return rc;
+    }
+    ba.pair_tile = c->d_pair_tile.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
     {
@@ -277,6 +288,19 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         ScopedSpan sp(c, ST_SORT);
         hipLaunchKernelGGL(k_sort_tiles, dim3(n_tiles), dim3(64), 0, c->stream, c->d_tile_start.as<uint32_t>(),
                            c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles);
+        SWR_HIP(c, hipGetLastError());
+    }
+    if (use_cover) {
+        ScopedSpan sp(c, ST_COVER);
+        CoverArgs ca;
+        ca.recs = c->d_recs.as<TriRec>();
+        ca.tile_list = c->d_tile_list.as<uint32_t>();
+        ca.pair_tile = c->d_pair_tile.as<uint32_t>();
+        ca.masks = c->d_masks.as<uint4>();
+        ca.counts = c->d_pcounts.as<uint16_t>();
+        ca.n_pairs = (uint32_t)total;
+        ca.fp = frame_params(c);
+        hipLaunchKernelGGL(k_cover, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, ca);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -296,10 +320,13 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         ra.clear_depth_on = c->pend_clear_depth ? 1 : 0;
         ra.blocks_x = (c->tiles_x + 1) / 2;
         ra.blocks_y = (c->band_ty1 - c->band_ty0 + 1) / 2;
+        ra.dbg = c->d_total.as<unsigned long long>() + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
         // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
         if (immediate) hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
         else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
-        else hipLaunchKernelGGL(k_raster_b, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        else if (c->raster_variant == 2) hipLaunchKernelGGL(k_raster_b, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
+        else hipLaunchKernelGGL(k_raster_c, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra,
+                                (const uint4*)c->d_masks.as<uint4>(), (const uint16_t*)c->d_pcounts.as<uint16_t>());
         SWR_HIP(c, hipGetLastError());
         c->pend_clear_color = c->pend_clear_depth = false;
     }
@@ -476,9 +503,10 @@ int swr_create(int device_id, swr_context** out) {
         g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
     }
     c->stream = c->own_stream;
-    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : 0; }
+    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : ((rv && !strcmp(rv, "b")) ? 2 : 0); }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
-    if (!rc) rc = ensure(c, c->d_total, 64);
+    if (!rc) rc = ensure(c, c->d_total, 256);
+    if (!rc && hipMemsetAsync(c->d_total.p, 0, 256, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (rc) { g_create_error = c->err; swr_destroy(c); return rc; }
     *out = c;
@@ -494,7 +522,7 @@ void swr_destroy(swr_context* c) {
     free_garbage(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_draws, &c->d_vblocks, &c->d_tblocks, &c->d_vout, &c->d_recs,
-                       &c->d_slot_tb, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
+                       &c->d_slot_tb, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -803,6 +831,16 @@ int swr_profile_reset(swr_context* c) {
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
     c->prof = {};
+    return SWR_OK;
+}
+
+int swr_debug_counters(swr_context* c, uint64_t out[8]) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    int rc = flush_locked(c); if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(out, c->d_total.as<unsigned long long>() + 8, 64, hipMemcpyDeviceToHost, c->stream));
+    if ((rc = sync_locked(c))) return rc;
+    SWR_HIP(c, hipMemsetAsync(c->d_total.as<unsigned long long>() + 8, 0, 64, c->stream));
     return SWR_OK;
 }
 

@@ -21,6 +21,7 @@ struct BinArgs {
     uint32_t* __restrict__ tile_count;   // COUNT: incremented; FILL: used as cursor (zeroed again before)
     const uint32_t* __restrict__ tile_start;
     uint32_t* __restrict__ tile_list;
+    uint32_t* __restrict__ pair_tile;    // FILL: band-local tile index of every pair (k_cover reads it)
     uint32_t list_capacity;
     Counters* __restrict__ counters;
 };
@@ -30,7 +31,7 @@ __device__ __forceinline__ void bin_one(const BinArgs& a, uint32_t tile, uint32_
     if (FILL) {
         uint32_t pos = atomicAdd(&a.tile_count[tile], 1u);
         uint32_t at = a.tile_start[tile] + pos;
-        if (at < a.list_capacity) a.tile_list[at] = slot;
+        if (at < a.list_capacity) { a.tile_list[at] = slot; a.pair_tile[at] = tile; }
         else a.counters->overflow = 1u;
     } else {
         atomicAdd(&a.tile_count[tile], 1u);

@@ -38,6 +38,7 @@ struct RasterArgs {
     float clear_rgba[4];
     int clear_color_on, clear_depth_on;
     int blocks_x, blocks_y;                // grid of 2x2-tile workgroups over the band
+    unsigned long long* dbg;               // SWR_DEBUG_COUNTERS builds only: 8 accumulators
 };
 
 // fragment inputs a built-in program may read

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
         L.owner[p] = 0xffffffffu;
     }
     unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+#ifdef SWR_DEBUG_COUNTERS
+    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_p1_iters = 0, dbg_chain_iters = 0, dbg_chunk_lanes = 0, dbg_shade_chunks = 0, dbg_tris = 0;
+#endif
 
     for (uint32_t base = 0; base < n;) {
         // ================= batch formation: as many triangles as fit the byte pool (>= 1) =================
@@ -138,6 +141,9 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
             }
             cnt = cur - rs;
         }
+#ifdef SWR_DEBUG_COUNTERS
+        { int mx = mine ? area : 0; for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off)); dbg_p1_iters += (unsigned)mx; ++dbg_batches; dbg_tris += (unsigned)B; }
+#endif
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         L.slot[lane] = slot;
@@ -147,7 +153,12 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
         n_tested += (unsigned)cnt;
 
         // ================= phase 2: lane per fragment, chunks in stream order =================
+#ifdef SWR_ABLATE_PHASE2
+        asm volatile("" :: "v"(total));
+        for (int pos = 0; pos < 0;) {
+#else
         for (int pos = 0; pos < total;) {
+#endif
             const int g = pos + lane;
             const bool valid = g < total;
             // triangle of fragment g: largest t with pre[t] <= g  (pre is non-decreasing, pre[0] = 0)
@@ -175,6 +186,9 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
             if (valid) L.owner[pix] = 0xffffffffu;
             const bool act = lane < cut;
+#ifdef SWR_DEBUG_COUNTERS
+            ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
+#endif
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             const int f_program = cdp->program, f_blend = cdp->blend, f_dt = cdp->depth_test;
@@ -192,15 +206,22 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
                 float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
                 float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
                 const int nrow = py - fsY, ncol = px - fsX;
+#ifdef SWR_DEBUG_COUNTERS
+                { int mx = nrow + ncol; for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off)); if (lane == 0) dbg_chain_iters += (unsigned)mx; }
+#endif
                 for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }
                 for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }
                 const float w0f = w0 * inv_area, w1f = w1 * inv_area, w2f = w2 * inv_area;               // :498-500
                 const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                         // :502
                 if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505
                     ++n_shaded;
+#ifdef SWR_ABLATE_SHADE
+                    const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
+#else
                     const float4 src = shade_fragment(cdp, f_program, (dflags >> 31) != 0u,
                                                       a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
                                                       a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
+#endif
                     if (src.w > 0.0f) {                                                                    // :511
                         const float4 dst = L.col[pix];
                         L.col[pix] = blend(src, dst, f_blend);                                             // :513-515
@@ -236,6 +257,13 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
         uint32_t* ts = a.tile_stats + 3u * tile;
         ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
     }
+#ifdef SWR_DEBUG_COUNTERS
+    if (lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[0], (unsigned long long)dbg_batches); atomicAdd(&a.dbg[1], (unsigned long long)dbg_chunks);
+        atomicAdd(&a.dbg[2], (unsigned long long)dbg_p1_iters); atomicAdd(&a.dbg[3], (unsigned long long)dbg_chain_iters);
+        atomicAdd(&a.dbg[4], (unsigned long long)dbg_chunk_lanes); atomicAdd(&a.dbg[5], (unsigned long long)dbg_tris);
+    }
+#endif
 }
 
 }  // namespace swr

@@ -1,0 +1,282 @@
+// swr_raster_c.hip.h -- k_cover + k_raster_c: coverage masks per (triangle, tile) pair, then a per-tile
+// fragment-stream kernel.  Same contract and arithmetic as k_raster (swr_raster.hip.h; reference
+// Rasterizer.cs:462-538); this is the fast path for every blend mode except None.
+//
+// k_cover   -- ONE LANE PER (triangle, tile) PAIR over the whole frame (pairs are the entries of the sorted
+//   tile lists, so waves are fully packed regardless of how few triangles a tile has).  Each lane walks the
+//   pixels of bbox /\ tile in exactly the reference's order with the reference's incremental float32 edge
+//   stepping (Rasterizer.cs:481-534) -- bit-exact by construction -- and records coverage (:493-494) as a
+//   256-bit mask (16 rows x 16 bits) plus its popcount.
+// k_raster_c -- one wave per 16x16 tile.  The tile's fragment stream is the concatenation, in submission
+//   order, of the set bits of its pairs' masks (row-major inside a pair = the reference's pixel order).  64
+//   consecutive fragments are taken at a time, one per lane; the chunk is cut at the first fragment whose pixel
+//   already occurs earlier in the chunk (ds_min owner election) or whose draw differs, so inside a chunk every
+//   pixel is touched once and state is uniform: depth test, Interpolate, fragment program, blend and the
+//   colour/Z update (tile-resident in LDS) are order-independent inside a chunk, and chunks run in stream order
+//   = the serial schedule of the reference (>= ties, blending, alpha-gated Z writes all exact).  Each fragment
+//   lane recomputes its own edge values by replaying its (y-startY)+(x-startX) add chain at full lane utilisation.
+#pragma once
+#include "swr_device.h"
+#include "swr_raster.hip.h"
+
+namespace swr {
+
+struct CoverArgs {
+    const TriRec* __restrict__ recs;
+    const uint32_t* __restrict__ tile_list;   // sorted: slot id per pair
+    const uint32_t* __restrict__ pair_tile;   // band-local tile index per pair
+    uint4* __restrict__ masks;                // 2 x uint4 per pair: row r -> bits (r & 1) * 16 .. of word r >> 1
+    uint16_t* __restrict__ counts;            // popcount of the mask
+    uint32_t n_pairs;
+    FrameParams fp;
+};
+
+__global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
+    __shared__ uint32_t s_mask[256][9];       // 8 words per lane (+1 pad: conflict-free row-per-lane access)
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    uint32_t* mrow = s_mask[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mrow[i] = 0u;
+    int cnt = 0;
+    if (p < a.n_pairs) {
+        const uint32_t slot = a.tile_list[p];
+        const uint32_t tile = a.pair_tile[p];
+        const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = a.fp.band_ty0 + (int)(tile / (uint32_t)a.fp.tiles_x);
+        const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
+        const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
+        const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
+        const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
+        const float s0x = r0.x, s1x = r0.y, s2x = r0.z, s0y = r0.w, s1y = r1.x, s2y = r1.y;
+        const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
+        const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
+        const int startY = max((int)(bby & 0xffffu), y0), endY = min((int)(bby >> 16), tile_end_y);
+        if (startX <= endX && startY <= endY) {                                                           // :476
+            const float a01 = s0y - s1y, b01 = s1x - s0x;                                                 // :445-447
+            const float a12 = s1y - s2y, b12 = s2x - s1x;
+            const float a20 = s2y - s0y, b20 = s0x - s2x;
+            const float fsx = (float)startX, fsy = (float)startY;
+            float w0r = a12 * (fsx - s1x) + b12 * (fsy - s1y);                                            // :481-483
+            float w1r = a20 * (fsx - s2x) + b20 * (fsy - s2y);
+            float w2r = a01 * (fsx - s0x) + b01 * (fsy - s0y);
+            float w0 = w0r, w1 = w1r, w2 = w2r;
+            const int area = (endX - startX + 1) * (endY - startY + 1);
+            int x = startX, y = startY;
+            uint32_t rowbits = 0;
+            for (int it = 0; it < area; ++it) {
+                const bool inside = (w0 >= 0 && w1 >= 0 && w2 >= 0) || (w0 <= 0 && w1 <= 0 && w2 <= 0);  // :493-494
+                rowbits |= inside ? (1u << (x - x0)) : 0u;
+                if (x == endX) {                                                                          // :532-534, :487-489
+                    const int rr = y - y0;
+                    mrow[rr >> 1] |= rowbits << ((rr & 1) * 16);
+                    cnt += __popc(rowbits);
+                    rowbits = 0;
+                    w0r += b12; w1r += b20; w2r += b01;
+                    w0 = w0r; w1 = w1r; w2 = w2r;
+                    x = startX; ++y;
+                } else {                                                                                  // :527-529
+                    w0 += a12; w1 += a20; w2 += a01;
+                    ++x;
+                }
+            }
+        }
+        a.masks[2 * (size_t)p] = make_uint4(mrow[0], mrow[1], mrow[2], mrow[3]);
+        a.masks[2 * (size_t)p + 1] = make_uint4(mrow[4], mrow[5], mrow[6], mrow[7]);
+        a.counts[p] = (uint16_t)cnt;
+    }
+}
+
+struct __attribute__((aligned(16))) WaveLdsC {
+    float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
+    float z[256];
+    uint32_t owner[256];             // chunk duplicate election (0xffffffff when idle)
+    uint32_t mask[64][8];            // batch: coverage masks
+    uint32_t slot[64];               // batch: triangle slot ids
+    uint32_t pre[64 + 4];            // batch: exclusive prefix of covered counts, pre[64] = total
+};
+
+// index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
+__device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
+    int base = 0;
+#pragma unroll
+    for (int width = 16; width >= 1; width >>= 1) {
+        const uint32_t lowmask = (width == 32) ? 0xffffffffu : ((1u << width) - 1u);
+        const int c = __popc((w >> base) & lowmask);
+        const bool up = k >= c;
+        k -= up ? c : 0;
+        base += up ? width : 0;
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(256) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+                                                  const uint16_t* __restrict__ counts) {
+    __shared__ WaveLdsC s_w[4];
+
+    const uint32_t nb = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;
+    const uint32_t blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + kk;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bx = (int)(blk % (uint32_t)a.blocks_x), by = (int)(blk / (uint32_t)a.blocks_x);
+    const int tx = bx * 2 + (wave & 1);
+    const int ty_local = by * 2 + (wave >> 1);
+    const int ty = a.fp.band_ty0 + ty_local;
+    if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
+    const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
+    const uint32_t n = a.tile_count[tile];
+    if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
+    const uint32_t start = a.tile_start[tile];
+    WaveLdsC& L = s_w[wave];
+
+    const int W = a.fp.width, H = a.fp.height;
+    const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
+
+    // ---- tile init: clear fused, or one coalesced read of the framebuffer ----
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int p = rr * 64 + lane;
+        const int gx = x0 + (p & 15), gy = y0 + (p >> 4);
+        const bool inb = gx < W && gy < H;
+        const size_t gi = (size_t)(gy - a.fp.band_y0) * (size_t)W + (size_t)gx;
+        float4 c;
+        if (a.clear_color_on) c = make_float4(a.clear_rgba[0], a.clear_rgba[1], a.clear_rgba[2], a.clear_rgba[3]);
+        else c = inb ? a.color[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float zz;
+        if (a.clear_depth_on) zz = SWR_FLOAT_MINVALUE;
+        else zz = inb ? a.depth[gi] : SWR_FLOAT_MINVALUE;
+        L.col[p] = c;
+        L.z[p] = zz;
+        L.owner[p] = 0xffffffffu;
+    }
+    unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+
+    for (uint32_t base = 0; base < n; base += 64u) {
+        // ---- batch: the next (up to) 64 pairs of this tile; masks and counts staged in LDS ----
+        const bool have = base + (uint32_t)lane < n;
+        const uint32_t pidx = start + base + (uint32_t)lane;
+        const uint32_t slot = have ? a.tile_list[pidx] : 0u;
+        const int cnt = have ? (int)counts[pidx] : 0;
+        uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
+        if (cnt > 0) { m0 = masks[2 * (size_t)pidx]; m1 = masks[2 * (size_t)pidx + 1]; }
+        const int cincl = wave_incl_scan(cnt, lane);
+        const int total = __shfl(cincl, 63);
+        if (total == 0) continue;
+        *reinterpret_cast<uint4*>(&L.mask[lane][0]) = m0;
+        *reinterpret_cast<uint4*>(&L.mask[lane][4]) = m1;
+        L.slot[lane] = slot;
+        L.pre[lane] = (uint32_t)(cincl - cnt);
+        if (lane == 0) L.pre[64] = (uint32_t)total;
+        n_tested += (unsigned)cnt;
+
+        // ---- fragment stream of the batch, 64 at a time ----
+        for (int pos = 0; pos < total;) {
+            const int g = pos + lane;
+            const bool valid = g < total;
+            // pair of fragment g: largest t with pre[t] <= g  (pre is non-decreasing, pre[0] = 0)
+            int lo = 0, hi = 64;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int mid = (lo + hi) >> 1;
+                const bool le = (int)L.pre[mid] <= g;
+                lo = le ? mid : lo;
+                hi = le ? hi : mid;
+            }
+            const int t = lo;
+            int k = valid ? g - (int)L.pre[t] : 0;
+            const uint32_t fslot = L.slot[t];
+            const TriRec* __restrict__ rp = a.recs + fslot;
+            const float4* __restrict__ fq = reinterpret_cast<const float4*>(rp);
+            const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
+            // k-th covered pixel of pair t in row-major order
+            const uint4 ma = *reinterpret_cast<const uint4*>(&L.mask[t][0]);
+            const uint4 mb = *reinterpret_cast<const uint4*>(&L.mask[t][4]);
+            int pix = 0;
+            {
+                const uint32_t wds[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
+                uint32_t wsel = wds[0];
+                int wi = 0;
+                bool found = false;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int c = __popc(wds[i]);
+                    const bool here = !found && k < c;
+                    wsel = here ? wds[i] : wsel;
+                    wi = here ? i : wi;
+                    found = found || here;
+                    k -= (!found) ? c : 0;
+                }
+                pix = wi * 32 + kth_set_bit32(wsel, valid && found ? k : 0);
+            }
+            // duplicate election: the lowest lane touching a pixel owns it; any other lane on that pixel must wait
+            if (valid) atomicMin(&L.owner[pix], (uint32_t)lane);
+            const uint32_t dflags = __float_as_uint(f3.w);
+            const uint32_t draw = dflags & 0x7fffffffu;
+            const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
+            const bool dup = valid && L.owner[pix] != (uint32_t)lane;
+            const unsigned long long stop = __ballot(!valid || dup || draw != draw0);
+            const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
+            if (valid) L.owner[pix] = 0xffffffffu;
+            const bool act = lane < cut;
+
+            const DrawParams* __restrict__ cdp = a.draws + draw0;
+            const int f_program = cdp->program, f_blend = cdp->blend, f_dt = cdp->depth_test;
+            if (act) {
+                const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
+                const float d0 = f1.z, d1 = f1.w, d2 = f2.x, inv_area = f2.y;
+                const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
+                const int fsX = max((int)(fbx & 0xffffu), x0), fsY = max((int)(fby & 0xffffu), y0);
+                const int px = x0 + (pix & 15), py = y0 + (pix >> 4);
+                const float a01 = t0y - t1y, b01 = t1x - t0x;
+                const float a12 = t1y - t2y, b12 = t2x - t1x;
+                const float a20 = t2y - t0y, b20 = t0x - t2x;
+                const float fsx = (float)fsX, fsy = (float)fsY;
+                float w0 = a12 * (fsx - t1x) + b12 * (fsy - t1y);                                         // :481-483
+                float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
+                float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
+                const int nrow = py - fsY, ncol = px - fsX;
+                for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }                       // :532-534
+                for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }                       // :527-529
+                const float w0f = w0 * inv_area, w1f = w1 * inv_area, w2f = w2 * inv_area;               // :498-500
+                const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                         // :502
+                if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505
+                    ++n_shaded;
+                    const float4 src = shade_fragment(cdp, f_program, (dflags >> 31) != 0u,
+                                                      a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
+                                                      a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
+                    if (src.w > 0.0f) {                                                                    // :511
+                        const float4 dst = L.col[pix];
+                        L.col[pix] = blend(src, dst, f_blend);                                             // :513-515
+                        if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = d;                                      // :517-518
+                        ++n_written;
+                    }
+                }
+            }
+            pos += cut;
+        }
+    }
+
+    // ---- write back: each wave store covers 4 rows x 256 B (colour) / 4 rows x 64 B (Z) ----
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int p = rr * 64 + lane;
+        const int gx = x0 + (p & 15), gy = y0 + (p >> 4);
+        if (gx < W && gy < H) {
+            const size_t gi = (size_t)(gy - a.fp.band_y0) * (size_t)W + (size_t)gx;
+            a.color[gi] = L.col[p];
+            a.depth[gi] = L.z[p];
+        }
+    }
+
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n_tested += (unsigned)__shfl_xor((int)n_tested, off);
+        n_shaded += (unsigned)__shfl_xor((int)n_shaded, off);
+        n_written += (unsigned)__shfl_xor((int)n_written, off);
+    }
+    if (lane == 0 && n > 0) {
+        uint32_t* ts = a.tile_stats + 3u * tile;
+        ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
+    }
+}
+
+}  // namespace swr

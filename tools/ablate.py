@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Timing-only A/B of kernel variants: for each EXTRA flag set, rebuild the library, run N frames of a config and print
+per-stage hipEvent times.  Outputs of ablated builds are wrong by design; the tracked library is restored afterwards.
+usage: ablate.py cfg3 "" "-DSWR_ABLATE_PHASE2" ..."""
+import os, shutil, subprocess, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "softwarerenderer_amd", "csrc")
+lib = os.path.join(ROOT, "softwarerenderer_amd", "libswr_hip.so")
+cfg = sys.argv[1]; variants = sys.argv[2:] or [""]
+child = r'''
+import sys, json; sys.path.insert(0, %r)
+from softwarerenderer_amd import Device, scenes
+scene = getattr(scenes, %r)()
+dev = Device(0); r = scenes.SceneRenderer(dev, scene)
+for _ in range(3): r.submit_frame(); dev.flush()
+dev.sync(); dev.profile_reset(); dev.profile_enable(True)
+N = 10
+for _ in range(N): r.submit_frame(); dev.flush()
+p = dev.profile(); print(json.dumps({k: round(v / N, 4) for k, v in p.items() if k.endswith("_ms")}))
+''' % (ROOT, cfg)
+shutil.copy(lib, lib + ".bak")
+try:
+    for v in variants:
+        subprocess.run(["make", "-C", csrc, "-s", "-B", f"EXTRA={v}"], check=True, stderr=subprocess.DEVNULL)
+        out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True)
+        print(f"{v or '(release)':40s}", out.stdout.strip() or out.stderr[-400:])
+finally:
+    shutil.move(lib + ".bak", lib)
