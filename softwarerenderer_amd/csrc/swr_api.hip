@@ -234,7 +234,9 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     int rc;
     BinArgs ba;
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
+    ba.recs = c->d_recs.as<TriRec>();
     ba.slot_lo = lo; ba.slot_hi = hi;
+    ba.width = c->W; ba.height = c->H;
     ba.tiles_x = c->tiles_x; ba.band_ty0 = c->band_ty0; ba.band_ty1 = c->band_ty1;
     ba.tile_count = c->d_tile_count.as<uint32_t>();
     ba.tile_start = c->d_tile_start.as<uint32_t>();

@@ -15,9 +15,11 @@ namespace swr {
 
 struct BinArgs {
     const unsigned long long* __restrict__ slot_tb;
+    const TriRec* __restrict__ recs;
     uint32_t slot_lo, slot_hi;           // slots [lo, hi) are binned in this round
     int tiles_x;
     int band_ty0, band_ty1;
+    int width, height;
     uint32_t* __restrict__ tile_count;   // COUNT: incremented; FILL: used as cursor (zeroed again before)
     const uint32_t* __restrict__ tile_start;
     uint32_t* __restrict__ tile_list;
@@ -25,6 +27,50 @@ struct BinArgs {
     uint32_t list_capacity;
     Counters* __restrict__ counters;
 };
+
+// Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
+// provably no pixel of bbox /\ tile can pass the reference's coverage test (all three incrementally stepped
+// float32 edge values >= 0, or all three <= 0; Rasterizer.cs:481-494).  The reference visits such tiles and
+// finds nothing, so dropping the pair changes no pixel and no counter.
+//
+// Proof sketch.  Let R be the pixel rectangle bbox /\ tile and, for edge k with float coefficients (a, b) and
+// reference vertex (rx, ry), E(x,y) = a*(x-rx) + b*(y-ry) in real arithmetic.  Every value the float chain
+// takes is fl-arithmetic on points of R: the start value costs <= 5 roundings of quantities bounded by
+// M = |a|*max|x-rx| + |b|*max|y-ry| over R, and each of the <= 30 chain adds rounds a value of magnitude
+// <= M(1+tiny); so |W - E| <= 35 * 2^-24 * M(1+tiny) at every pixel of R.  With delta = 64 * 2^-24 * M:
+// max_R E < -delta  =>  W < 0 on all of R (kills "all >= 0");  min_R E > delta  =>  W > 0 on all of R (kills
+// "all <= 0").  E is linear, so its extrema over R are at corners; they are evaluated in fp64, where the
+// products (24-bit x <= 29-bit) are exact and the one addition's error is ~2^-29 of delta.  NaN / Inf inputs
+// make every comparison false, i.e. "keep".
+__device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy[3], int minX, int maxX, int minY, int maxY,
+                                               int tx, int ty, int width, int height) {
+    const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
+    const int startX = max(minX, x0), endX = min(maxX, min(x0 + SWR_TILE - 1, width - 1));
+    const int startY = max(minY, y0), endY = min(maxY, min(y0 + SWR_TILE - 1, height - 1));
+    if (startX > endX || startY > endY) return false;                 // Rasterizer.cs:476: nothing visited
+    // edge k: coefficients exactly as RasterizeTriangle forms them (Rasterizer.cs:445-447), reference vertex :481-483
+    const float ea[3] = { sy[1] - sy[2], sy[2] - sy[0], sy[0] - sy[1] };   // a12, a20, a01
+    const float eb[3] = { sx[2] - sx[1], sx[0] - sx[2], sx[1] - sx[0] };   // b12, b20, b01
+    const float rx[3] = { sx[1], sx[2], sx[0] };
+    const float ry[3] = { sy[1], sy[2], sy[0] };
+    bool any_neg = false, any_pos = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = (double)ea[k], b = (double)eb[k];
+        const double dxs = (double)startX - (double)rx[k], dxe = (double)endX - (double)rx[k];
+        const double dys = (double)startY - (double)ry[k], dye = (double)endY - (double)ry[k];
+        const double ax_s = a * dxs, ax_e = a * dxe, by_s = b * dys, by_e = b * dye;
+        const double emax = fmax(ax_s, ax_e) + fmax(by_s, by_e);
+        const double emin = fmin(ax_s, ax_e) + fmin(by_s, by_e);
+        const double m = fabs(a) * fmax(fabs(dxs), fabs(dxe)) + fabs(b) * fmax(fabs(dys), fabs(dye));
+        const double delta = m * (64.0 / 16777216.0);
+        // fmax/fmin drop NaNs, so test finiteness explicitly: a non-finite term means "cannot prove anything"
+        const bool finite = (m == m) && (m < 1.0e300);
+        any_neg = any_neg || (finite && emax < -delta);
+        any_pos = any_pos || (finite && emin > delta);
+    }
+    return !(any_neg && any_pos);
+}
 
 template <bool FILL>
 __device__ __forceinline__ void bin_one(const BinArgs& a, uint32_t tile, uint32_t slot) {
@@ -44,6 +90,8 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     const uint32_t slot = a.slot_lo + blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tminx = 0, tminy = 0, nx = 0, ny = 0;
+    float sx[3] = { 0.f, 0.f, 0.f }, sy[3] = { 0.f, 0.f, 0.f };
+    int minX = 0, maxX = -1, minY = 0, maxY = -1;
     if (slot < a.slot_hi) {
         unsigned long long tb = a.slot_tb[slot];
         if (tb != SWR_TB_INVALID) {
@@ -56,6 +104,13 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
             nx = tmaxx - tminx + 1;
             ny = tmaxy - tminy + 1;
             if (ny <= 0) { nx = 0; ny = 0; }
+            else {
+                const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
+                const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
+                sx[0] = r0.x; sx[1] = r0.y; sx[2] = r0.z; sy[0] = r0.w; sy[1] = r1.x; sy[2] = r1.y;
+                const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
+                minX = (int)(bbx & 0xffffu); maxX = (int)(bbx >> 16); minY = (int)(bby & 0xffffu); maxY = (int)(bby >> 16);
+            }
         }
     }
     const int nt = nx * ny;
@@ -63,7 +118,8 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     if (!big) {
         for (int i = 0; i < nt; ++i) {
             int ty = tminy + i / nx, tx = tminx + i % nx;
-            bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
+            if (pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height))
+                bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
         }
     }
     unsigned long long m = __ballot(big);
@@ -73,36 +129,55 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
         const int s_tminx = __shfl(tminx, src), s_tminy = __shfl(tminy, src);
         const int s_nx = __shfl(nx, src), s_nt = __shfl(nt, src);
         const uint32_t s_slot = (uint32_t)__shfl((int)slot, src);
+        float bsx[3], bsy[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
+        const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
         for (int i = lane; i < s_nt; i += 64) {
             int ty = s_tminy + i / s_nx, tx = s_tminx + i % s_nx;
-            bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), s_slot);
+            if (pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height))
+                bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), s_slot);
         }
     }
 }
 
-// single-workgroup exclusive scan over the band's tiles (<= 512x512 tiles at 8192^2)
+// single-workgroup exclusive scan over the band's tiles (<= 512x512 tiles at 8192^2): 4096 elements per
+// iteration with coalesced 16-byte loads, wave-shuffle scans and a running carry
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
                                                uint32_t n, unsigned long long* __restrict__ total_out) {
-    __shared__ unsigned long long s_sum[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n + 1023u) / 1024u;
-    const uint32_t lo = min(tid * per, n), hi = min(lo + per, n);
-    unsigned long long sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += count[i];
-    s_sum[tid] = sum;
+    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    if (tid == 0) s_carry = 0ull;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {        // Hillis-Steele inclusive scan
-        unsigned long long v = (tid >= off) ? s_sum[tid - off] : 0ull;
+    for (uint32_t base = 0; base < n; base += 4096u) {
+        const uint32_t i0 = base + tid * 4u;
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = (i0 + j < n) ? count[i0 + j] : 0u;
+        unsigned long long mine = (unsigned long long)c[0] + c[1] + c[2] + c[3];
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            unsigned lo = (unsigned)incl, hi = (unsigned)(incl >> 32);
+            unsigned long long o = ((unsigned long long)(unsigned)__shfl_up((int)hi, off) << 32) | (unsigned)__shfl_up((int)lo, off);
+            if (lane >= (uint32_t)off) incl += o;
+        }
+        if (lane == 63u) s_wave[wv] = incl;
         __syncthreads();
-        s_sum[tid] += v;
+        unsigned long long wave_off = 0;
+        for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
+        unsigned long long run = s_carry + wave_off + (incl - mine);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (i0 + j < n) start[i0 + j] = (uint32_t)min(run, 0xffffffffull);
+            run += c[j];
+        }
+        __syncthreads();
+        if (tid == 1023u) s_carry = run;
         __syncthreads();
     }
-    unsigned long long run = s_sum[tid] - sum;              // exclusive prefix of this thread's chunk
-    for (uint32_t i = lo; i < hi; ++i) {
-        start[i] = (uint32_t)min(run, 0xffffffffull);
-        run += count[i];
-    }
-    if (tid == 1023) *total_out = s_sum[1023];
+    if (tid == 0) *total_out = s_carry;
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------
