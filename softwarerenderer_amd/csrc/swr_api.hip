@@ -241,7 +241,6 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     ba.tile_count = c->d_tile_count.as<uint32_t>();
     ba.tile_start = c->d_tile_start.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
-    ba.pair_tile = c->d_pair_tile.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
     const uint32_t bin_blocks = (hi - lo + 255u) / 256u;
@@ -250,8 +249,11 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
         hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, ba.tile_count, c->d_tile_start.as<uint32_t>(),
-                           n_tiles, c->d_total.as<unsigned long long>());
+        const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
+        unsigned long long* sums = c->d_total.as<unsigned long long>() + 32;      // room for 1024 block sums
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count,
+                           c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, c->d_total.as<unsigned long long>());
         SWR_HIP(c, hipGetLastError());
     }
     SWR_HIP(c, hipMemcpyAsync(&total, c->d_total.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -277,7 +279,6 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         if ((rc = ensure(c, c->d_masks, (size_t)total * 32))) return rc;
         if ((rc = ensure(c, c->d_pcounts, (size_t)total * 2 + 64))) return rc;
     }
-    ba.pair_tile = c->d_pair_tile.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
     {
@@ -289,7 +290,7 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     {
         ScopedSpan sp(c, ST_SORT);
         hipLaunchKernelGGL(k_sort_tiles, dim3(n_tiles), dim3(64), 0, c->stream, c->d_tile_start.as<uint32_t>(),
-                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles);
+                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>());
         SWR_HIP(c, hipGetLastError());
     }
     if (use_cover) {
@@ -327,7 +328,7 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         if (immediate) hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
         else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
         else if (c->raster_variant == 2) hipLaunchKernelGGL(k_raster_b, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
-        else hipLaunchKernelGGL(k_raster_c, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra,
+        else hipLaunchKernelGGL(k_raster_c, dim3((unsigned)(ra.blocks_x * ra.blocks_y) * (4u / SWR_RASTER_WPB)), dim3(64 * SWR_RASTER_WPB), 0, c->stream, ra,
                                 (const uint4*)c->d_masks.as<uint4>(), (const uint16_t*)c->d_pcounts.as<uint16_t>());
         SWR_HIP(c, hipGetLastError());
         c->pend_clear_color = c->pend_clear_depth = false;
@@ -507,8 +508,8 @@ int swr_create(int device_id, swr_context** out) {
     c->stream = c->own_stream;
     { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : ((rv && !strcmp(rv, "b")) ? 2 : 0); }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
-    if (!rc) rc = ensure(c, c->d_total, 256);
-    if (!rc && hipMemsetAsync(c->d_total.p, 0, 256, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
+    if (!rc) rc = ensure(c, c->d_total, 256 + 1024 * 8);
+    if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 1024 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (rc) { g_create_error = c->err; swr_destroy(c); return rc; }
     *out = c;

@@ -23,7 +23,6 @@ struct BinArgs {
     uint32_t* __restrict__ tile_count;   // COUNT: incremented; FILL: used as cursor (zeroed again before)
     const uint32_t* __restrict__ tile_start;
     uint32_t* __restrict__ tile_list;
-    uint32_t* __restrict__ pair_tile;    // FILL: band-local tile index of every pair (k_cover reads it)
     uint32_t list_capacity;
     Counters* __restrict__ counters;
 };
@@ -72,15 +71,38 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
     return !(any_neg && any_pos);
 }
 
+// Adds (tile, slot) pairs for the lanes with want == true.  Lanes of a wave usually hold neighbouring triangles
+// of one mesh, i.e. few distinct tiles: one atomic per DISTINCT tile per call (leader election by ballot),
+// ranks inside the group by mbcnt.  The order inside a tile's list is irrelevant here (k_sort_tiles fixes it).
 template <bool FILL>
-__device__ __forceinline__ void bin_one(const BinArgs& a, uint32_t tile, uint32_t slot) {
+__device__ __forceinline__ void bin_wave(const BinArgs& a, bool want, uint32_t tile, uint32_t slot) {
+    const int lane = (int)(threadIdx.x & 63u);
+    unsigned long long todo = __ballot(want);
+    int my_leader = lane;
+    uint32_t my_rank = 0, base_reg = 0;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t t0 = (uint32_t)__shfl((int)tile, leader);
+        const bool in_group = want && tile == t0;
+        const unsigned long long same = __ballot(in_group);
+        if (in_group) {
+            my_leader = leader;
+            my_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+        }
+        if (lane == leader) {
+            // the returned base is only consumed after the loop, so the atomics of all groups are in flight together
+            if (FILL) base_reg = atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
+            else atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
+        }
+        todo &= ~same;
+    }
     if (FILL) {
-        uint32_t pos = atomicAdd(&a.tile_count[tile], 1u);
-        uint32_t at = a.tile_start[tile] + pos;
-        if (at < a.list_capacity) { a.tile_list[at] = slot; a.pair_tile[at] = tile; }
-        else a.counters->overflow = 1u;
-    } else {
-        atomicAdd(&a.tile_count[tile], 1u);
+        const uint32_t base = (uint32_t)__shfl((int)base_reg, my_leader);
+        if (want) {
+            const uint32_t at = a.tile_start[tile] + base + my_rank;
+            if (at < a.list_capacity) a.tile_list[at] = slot;
+            else a.counters->overflow = 1u;
+        }
     }
 }
 
@@ -115,11 +137,18 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     }
     const int nt = nx * ny;
     const bool big = nt > 8;
-    if (!big) {
-        for (int i = 0; i < nt; ++i) {
-            int ty = tminy + i / nx, tx = tminx + i % nx;
-            if (pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height))
-                bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
+    {
+        int nt_small = big ? 0 : nt, nt_max = nt_small;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nt_max = max(nt_max, __shfl_xor(nt_max, off));
+        for (int i = 0; i < nt_max; ++i) {
+            bool want = i < nt_small;
+            int ty = 0, tx = 0;
+            if (want) {
+                ty = tminy + i / nx; tx = tminx + i % nx;
+                want = pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height);
+            }
+            bin_wave<FILL>(a, want, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
         }
     }
     unsigned long long m = __ballot(big);
@@ -133,51 +162,76 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
         const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
-        for (int i = lane; i < s_nt; i += 64) {
-            int ty = s_tminy + i / s_nx, tx = s_tminx + i % s_nx;
-            if (pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height))
-                bin_one<FILL>(a, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), s_slot);
+        for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
+            const int i = i0 + lane;
+            bool want = i < s_nt;
+            int ty = 0, tx = 0;
+            if (want) {
+                ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
+                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height);
+            }
+            if (want) {
+                const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                if (FILL) {
+                    const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
+                    if (at < a.list_capacity) a.tile_list[at] = s_slot;
+                    else a.counters->overflow = 1u;
+                } else {
+                    atomicAdd(&a.tile_count[tile], 1u);
+                }
+            }
         }
     }
 }
 
-// single-workgroup exclusive scan over the band's tiles (<= 512x512 tiles at 8192^2): 4096 elements per
-// iteration with coalesced 16-byte loads, wave-shuffle scans and a running carry
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
-                                               uint32_t n, unsigned long long* __restrict__ total_out) {
-    __shared__ unsigned long long s_wave[16];
-    __shared__ unsigned long long s_carry;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid == 0) s_carry = 0ull;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 4096u) {
-        const uint32_t i0 = base + tid * 4u;
-        uint32_t c[4];
+// Exclusive scan of the per-tile counts in two launches (no inter-block waiting, no dispatch-order assumption):
+//   k_scan_sums : block b sums its 1024 counts -> sums[b]
+//   k_scan_apply: block b adds sums[0..b) (<= 256 values at 8192^2) to a local scan of its 1024 counts
+__device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long* s_part) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) c[j] = (i0 + j < n) ? count[i0 + j] : 0u;
-        unsigned long long mine = (unsigned long long)c[0] + c[1] + c[2] + c[3];
-        unsigned long long incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            unsigned lo = (unsigned)incl, hi = (unsigned)(incl >> 32);
-            unsigned long long o = ((unsigned long long)(unsigned)__shfl_up((int)hi, off) << 32) | (unsigned)__shfl_up((int)lo, off);
-            if (lane >= (uint32_t)off) incl += o;
-        }
-        if (lane == 63u) s_wave[wv] = incl;
-        __syncthreads();
-        unsigned long long wave_off = 0;
-        for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
-        unsigned long long run = s_carry + wave_off + (incl - mine);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (i0 + j < n) start[i0 + j] = (uint32_t)min(run, 0xffffffffull);
-            run += c[j];
-        }
-        __syncthreads();
-        if (tid == 1023u) s_carry = run;
-        __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        v += ((unsigned long long)(unsigned)__shfl_xor((int)hi, off) << 32) | (unsigned)__shfl_xor((int)lo, off);
     }
-    if (tid == 0) *total_out = s_carry;
+    if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned long long t = 0;
+    for (int w = 0; w < 16; ++w) t += s_part[w];
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
+                                                    unsigned long long* __restrict__ sums) {
+    __shared__ unsigned long long s_part[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    const unsigned long long t = block_sum_1024(i < n ? count[i] : 0u, s_part);
+    if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
+                                                     uint32_t n, const unsigned long long* __restrict__ sums,
+                                                     unsigned long long* __restrict__ total_out) {
+    __shared__ unsigned long long s_part[16];
+    __shared__ unsigned long long s_wave[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // offset of this block = sum of the earlier blocks' sums (gridDim.x <= 1024)
+    const unsigned long long off = block_sum_1024(tid < blockIdx.x ? sums[tid] : 0ull, s_part);
+    const uint32_t i = blockIdx.x * 1024u + tid;
+    const uint32_t c = i < n ? count[i] : 0u;
+    unsigned long long incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        unsigned lo = (unsigned)incl, hi = (unsigned)(incl >> 32);
+        unsigned long long v = ((unsigned long long)(unsigned)__shfl_up((int)hi, o) << 32) | (unsigned)__shfl_up((int)lo, o);
+        if (lane >= (uint32_t)o) incl += v;
+    }
+    if (lane == 63u) s_wave[wv] = incl;
+    __syncthreads();
+    unsigned long long wave_off = 0;
+    for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
+    const unsigned long long excl = off + wave_off + incl - c;
+    if (i < n) start[i] = (uint32_t)min(excl, 0xffffffffull);
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023u) *total_out = excl + c;
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------
@@ -202,14 +256,18 @@ __device__ __forceinline__ void cmpx_glb(uint32_t* g, uint32_t i, uint32_t p, ui
 // one 64-thread block (one wave) per tile
 __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
-                                                   uint32_t* __restrict__ tile_list, uint32_t n_tiles) {
+                                                   uint32_t* __restrict__ tile_list, uint32_t n_tiles,
+                                                   uint32_t* __restrict__ pair_tile) {
     __shared__ uint32_t s_keys[SWR_SORT_LDS];
     const uint32_t tile = blockIdx.x;
     if (tile >= n_tiles) return;
     const uint32_t n = tile_count[tile];
+    if (n == 0) return;
+    const uint32_t lane = threadIdx.x;
+    // band-local tile index of every pair of this segment (k_cover reads it): contiguous, coalesced
+    for (uint32_t i = lane; i < n; i += 64) pair_tile[tile_start[tile] + i] = tile;
     if (n < 2) return;
     uint32_t* seg = tile_list + tile_start[tile];
-    const uint32_t lane = threadIdx.x;
 
     if (n <= 64) {                                   // in registers, cross-lane shuffles
         uint32_t key = lane < n ? seg[lane] : 0xffffffffu;

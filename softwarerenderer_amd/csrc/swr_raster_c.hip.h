@@ -108,18 +108,31 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
     return base;
 }
 
-__global__ __launch_bounds__(256) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
-                                                  const uint16_t* __restrict__ counts) {
-    __shared__ WaveLdsC s_w[4];
+// SWR_RASTER_WPB waves (tiles) per workgroup: 1 lets the dispatcher backfill a finished tile's slot at once
+// (tile list lengths vary a lot), 4 shares one workgroup launch between a 2x2 tile quad.
+#ifndef SWR_RASTER_WPB
+#define SWR_RASTER_WPB 1
+#endif
+__global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+                                                                  const uint16_t* __restrict__ counts) {
+    __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
 
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;
     const uint32_t blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + kk;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#if SWR_RASTER_WPB == 4
     const int bx = (int)(blk % (uint32_t)a.blocks_x), by = (int)(blk / (uint32_t)a.blocks_x);
     const int tx = bx * 2 + (wave & 1);
     const int ty_local = by * 2 + (wave >> 1);
+#else
+    // one tile per workgroup; walk tiles in 2x2 quads so that neighbours (shared triangles) run close in time
+    const uint32_t quad = blk >> 2, sub = blk & 3u;
+    const int bx = (int)(quad % (uint32_t)a.blocks_x), by = (int)(quad / (uint32_t)a.blocks_x);
+    const int tx = bx * 2 + (int)(sub & 1u);
+    const int ty_local = by * 2 + (int)(sub >> 1);
+#endif
     const int ty = a.fp.band_ty0 + ty_local;
     if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
     const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
@@ -181,7 +194,11 @@ __global__ __launch_bounds__(256) void k_raster_c(RasterArgs a, const uint4* __r
                 lo = le ? mid : lo;
                 hi = le ? hi : mid;
             }
+#ifdef SWR_ABLATE_SEARCH
+            const int t = (lane >> 4) & 3; asm volatile("" :: "v"(lo));
+#else
             const int t = lo;
+#endif
             int k = valid ? g - (int)L.pre[t] : 0;
             const uint32_t fslot = L.slot[t];
             const TriRec* __restrict__ rp = a.recs + fslot;
@@ -207,6 +224,9 @@ __global__ __launch_bounds__(256) void k_raster_c(RasterArgs a, const uint4* __r
                 }
                 pix = wi * 32 + kth_set_bit32(wsel, valid && found ? k : 0);
             }
+#ifdef SWR_ABLATE_KTH
+            asm volatile("" :: "v"(pix)); pix = (g * 7) & 255;
+#endif
             // duplicate election: the lowest lane touching a pixel owns it; any other lane on that pixel must wait
             if (valid) atomicMin(&L.owner[pix], (uint32_t)lane);
             const uint32_t dflags = __float_as_uint(f3.w);
@@ -234,15 +254,23 @@ __global__ __launch_bounds__(256) void k_raster_c(RasterArgs a, const uint4* __r
                 float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
                 float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
                 const int nrow = py - fsY, ncol = px - fsX;
+#ifndef SWR_ABLATE_CHAIN
                 for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }                       // :532-534
                 for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }                       // :527-529
+#else
+                w0 += (float)nrow * b12 + (float)ncol * a12; w1 += (float)nrow * b20 + (float)ncol * a20; w2 += (float)nrow * b01 + (float)ncol * a01;
+#endif
                 const float w0f = w0 * inv_area, w1f = w1 * inv_area, w2f = w2 * inv_area;               // :498-500
                 const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                         // :502
                 if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505
                     ++n_shaded;
+#ifdef SWR_ABLATE_SHADE
+                    const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
+#else
                     const float4 src = shade_fragment(cdp, f_program, (dflags >> 31) != 0u,
                                                       a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
                                                       a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
+#endif
                     if (src.w > 0.0f) {                                                                    // :511
                         const float4 dst = L.col[pix];
                         L.col[pix] = blend(src, dst, f_blend);                                             // :513-515
