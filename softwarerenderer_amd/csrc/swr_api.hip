@@ -50,9 +50,21 @@ enum Stage { ST_VERTEX = 0, ST_SETUP, ST_BIN, ST_SORT, ST_COVER, ST_RASTER, ST_C
 
 struct EventSpan { int stage; hipEvent_t a, b; };
 
+#define SWR_SLOTS 3
+struct FrameSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
+
 struct DrawCmd {
     DrawParams p;
     swr_mesh* mesh;
+};
+
+// one flush = one batch; kept until the host has seen that it fitted (optimistic execution, see swr::Ctrl)
+struct Batch {
+    std::vector<DrawCmd> draws;
+    bool clear_color = false, clear_depth = false;
+    float clear_rgba[4] = { 0, 0, 0, 0 };
+    float near_clip = 0.1f;
+    uint32_t seq = 0;
 };
 
 }  // namespace
@@ -82,12 +94,19 @@ struct swr_context {
     std::vector<DrawCmd> draws;
     uint64_t pend_verts = 0, pend_tris = 0;
     std::vector<swr_mesh*> garbage;           // transient meshes to free at the next sync point
+    std::vector<Batch> inflight;              // launched optimistically, not yet validated
+    uint32_t next_seq = 1;
+    bool sync_flush = false;                  // SWR_SYNC_FLUSH=1: read the pair total back in every flush
 
-    DevBuf d_draws, d_vblocks, d_tblocks, d_vout, d_recs, d_slot_tb;
-    DevBuf d_pair_tile, d_masks, d_pcounts;
+    DevBuf d_upload, d_vout, d_recs, d_slot_tb;   // d_upload = draws | vertex block map | triangle block map of the running batch
+    FrameSlot slots[SWR_SLOTS];
+    uint32_t slot_next = 0;
+    DevBuf d_pair_tile, d_masks, d_pcounts, d_ctrl;
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
+    unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
+    unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
 
     bool profiling = false;
     bool force_immediate = false;             // SWR_RASTER=imm: always use k_raster (A/B and tests)
@@ -123,6 +142,29 @@ int ensure(swr_context* c, DevBuf& b, size_t bytes, bool zero_new = false) {
 }
 
 void release(DevBuf& b) { if (b.p) (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+// Frame-slot ring: a batch takes the next slot = {pinned staging block for its upload, completion event}.
+// Taking a slot first waits for the batch that used it SWR_SLOTS flushes ago, which (a) makes the pinned block
+// safe to overwrite and (b) bounds how far the host runs ahead of the GPU (pageable uploads and unbounded
+// queue depth both serialise the stream on some HIP runtimes).
+void* slot_acquire(swr_context* c, size_t bytes) {
+    FrameSlot& fs = c->slots[c->slot_next % SWR_SLOTS];
+    if (fs.busy) { (void)hipEventSynchronize(fs.done); fs.busy = false; }
+    if (fs.cap < bytes) {
+        if (fs.host) (void)hipHostFree(fs.host);
+        fs.host = nullptr; fs.cap = 0;
+        size_t cap = std::max<size_t>(bytes + bytes / 2, 1 << 16);
+        if (hipHostMalloc(&fs.host, cap, hipHostMallocDefault) != hipSuccess) { fs.host = nullptr; return nullptr; }
+        fs.cap = cap;
+    }
+    return fs.host;
+}
+void slot_submit(swr_context* c) {            // call after the batch's last launch
+    FrameSlot& fs = c->slots[c->slot_next % SWR_SLOTS];
+    if (!fs.done) (void)hipEventCreateWithFlags(&fs.done, hipEventDisableTiming);
+    if (fs.done && hipEventRecord(fs.done, c->stream) == hipSuccess) fs.busy = true;
+    c->slot_next++;
+}
 
 int band_y0(const swr_context* c) { return c->band_ty0 * SWR_TILE; }
 int band_rows(const swr_context* c) {
@@ -206,32 +248,53 @@ void free_garbage(swr_context* c) {       // stream must be idle
     c->garbage.clear();
 }
 
+int validate_locked(swr_context* c);
+
 int sync_locked(swr_context* c) {
     SWR_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = validate_locked(c);
     collect_spans(c);
     free_garbage(c);
-    return SWR_OK;
+    for (auto& fs : c->slots) fs.busy = false;     // stream idle: every slot is free
+    return rc;
 }
 
-int run_clear(swr_context* c) {
+enum { MODE_SYNC = 0, MODE_ASYNC = 1 };
+const unsigned long long kMaxPairs = 1ull << 30;       // list entries per round (4 GiB of slot ids)
+
+size_t pair_capacity(const swr_context* c) {
+    return std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 2));
+}
+int ensure_pairs(swr_context* c, size_t n) {
+    int rc;
+    if ((rc = ensure(c, c->d_tile_list, n * 4))) return rc;
+    if ((rc = ensure(c, c->d_pair_tile, n * 4))) return rc;
+    if ((rc = ensure(c, c->d_masks, n * 32))) return rc;
+    return ensure(c, c->d_pcounts, n * 2 + 64);
+}
+
+int run_clear(swr_context* c, bool& cc, bool& cd, const float rgba_[4]) {
     size_t n = band_pixels(c);
-    if (n && (c->pend_clear_color || c->pend_clear_depth)) {
+    if (n && (cc || cd)) {
         ScopedSpan sp(c, ST_CLEAR);
         int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
-        float4 rgba = make_float4(c->clear_rgba[0], c->clear_rgba[1], c->clear_rgba[2], c->clear_rgba[3]);
+        float4 rgba = make_float4(rgba_[0], rgba_[1], rgba_[2], rgba_[3]);
         hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, c->stream, c->color, c->depth, n, rgba,
-                           c->pend_clear_color ? 1 : 0, c->pend_clear_depth ? 1 : 0);
+                           cc ? 1 : 0, cd ? 1 : 0, (const Ctrl*)c->d_ctrl.as<Ctrl>());
         SWR_HIP(c, hipGetLastError());
     }
-    c->pend_clear_color = c->pend_clear_depth = false;
+    cc = cd = false;
     return SWR_OK;
 }
 
-// bins slots [lo, hi) and rasterises them; splits the range when the pair list would not fit
-int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
+// bins slots [lo, hi) and rasterises them.  MODE_SYNC reads the pair total back (sizes buffers exactly, splits a
+// range that would need more than kMaxPairs entries); MODE_ASYNC launches everything against the current capacity.
+int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, bool immediate, int mode) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
+    const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
+    unsigned long long* d_total = c->d_total.as<unsigned long long>();
     BinArgs ba;
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
     ba.recs = c->d_recs.as<TriRec>();
@@ -241,46 +304,50 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     ba.tile_count = c->d_tile_count.as<uint32_t>();
     ba.tile_start = c->d_tile_start.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
-    ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
+    ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
+    ba.ctrl = ctrl;
+    ba.total = d_total;
     const uint32_t bin_blocks = (hi - lo + 255u) / 256u;
-    unsigned long long total = 0;
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
         hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
         const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
-        unsigned long long* sums = c->d_total.as<unsigned long long>() + 32;      // room for 1024 block sums
+        unsigned long long* sums = d_total + 32;      // room for 1024 block sums
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
+        // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
+        const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
         hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count,
-                           c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, c->d_total.as<unsigned long long>());
+                           c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
+                           cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
+                           mode == MODE_ASYNC ? 1 : 0);
         SWR_HIP(c, hipGetLastError());
     }
-    SWR_HIP(c, hipMemcpyAsync(&total, c->d_total.p, 8, hipMemcpyDeviceToHost, c->stream));
-    SWR_HIP(c, hipStreamSynchronize(c->stream));
-
-    const unsigned long long max_pairs = 1ull << 30;       // 4 GiB of list entries per round
-    if (total > max_pairs && hi - lo > 2) {
-        // too many (triangle, tile) pairs for one round: split the slot range.  Order is preserved
-        // because the framebuffer carries the state from one round to the next.
-        uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
-        if (mid == lo) mid = lo + 2;
-        if ((rc = bin_and_raster(c, lo, mid, immediate))) return rc;
-        return bin_and_raster(c, mid, hi, immediate);
+    uint32_t cover_items = ba.list_capacity;          // async: grid covers the whole capacity, lanes beyond the total exit
+    if (mode == MODE_SYNC) {
+        unsigned long long total = 0;
+        SWR_HIP(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        SWR_HIP(c, hipStreamSynchronize(c->stream));
+        if (total > kMaxPairs && hi - lo > 2) {
+            // too many (triangle, tile) pairs for one round: split the slot range.  Order is preserved
+            // because the framebuffer carries the state from one round to the next.
+            uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
+            if (mid == lo) mid = lo + 2;
+            if ((rc = bin_and_raster(c, b, cc, cd, lo, mid, immediate, mode))) return rc;
+            return bin_and_raster(c, b, cc, cd, mid, hi, immediate, mode);
+        }
+        Counters* tp = c->d_counters.as<Counters>() + 64;          // tile_pairs of a round that really runs
+        if (total == 0) return run_clear(c, cc, cd, b.clear_rgba);
+        if (total > 0xffffffffull) return fail(c, SWR_ERR_UNSUPPORTED, "a single triangle covers more tile pairs than one round can hold");
+        c->host_tile_pairs += total; (void)tp;
+        // a little headroom so that the next, similar frame can run without reading the total back
+        if ((rc = ensure_pairs(c, (size_t)std::min<unsigned long long>(total + total / 4 + 4096, std::max(total, kMaxPairs))))) return rc;
+        ba.tile_list = c->d_tile_list.as<uint32_t>();
+        ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
+        cover_items = (uint32_t)total;
     }
-    c->totals.tile_pairs += total;
-    if (total == 0) return run_clear(c);
-    if (total > 0xffffffffull) return fail(c, SWR_ERR_UNSUPPORTED, "a single triangle covers more tile pairs than one round can hold");
-
-    if ((rc = ensure(c, c->d_tile_list, (size_t)total * 4))) return rc;
-    if ((rc = ensure(c, c->d_pair_tile, (size_t)total * 4))) return rc;
     const bool use_cover = !immediate && c->raster_variant == 0;
-    if (use_cover) {
-        if ((rc = ensure(c, c->d_masks, (size_t)total * 32))) return rc;
-        if ((rc = ensure(c, c->d_pcounts, (size_t)total * 2 + 64))) return rc;
-    }
-    ba.tile_list = c->d_tile_list.as<uint32_t>();
-    ba.list_capacity = (uint32_t)std::min<size_t>(c->d_tile_list.cap / 4, 0xffffffffu);
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
@@ -290,10 +357,10 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
     {
         ScopedSpan sp(c, ST_SORT);
         hipLaunchKernelGGL(k_sort_tiles, dim3(n_tiles), dim3(64), 0, c->stream, c->d_tile_start.as<uint32_t>(),
-                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>());
+                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl);
         SWR_HIP(c, hipGetLastError());
     }
-    if (use_cover) {
+    if (use_cover && cover_items) {
         ScopedSpan sp(c, ST_COVER);
         CoverArgs ca;
         ca.recs = c->d_recs.as<TriRec>();
@@ -301,75 +368,74 @@ int bin_and_raster(swr_context* c, uint32_t lo, uint32_t hi, bool immediate) {
         ca.pair_tile = c->d_pair_tile.as<uint32_t>();
         ca.masks = c->d_masks.as<uint4>();
         ca.counts = c->d_pcounts.as<uint16_t>();
-        ca.n_pairs = (uint32_t)total;
+        ca.n_pairs = d_total;
+        ca.ctrl = ctrl;
         ca.fp = frame_params(c);
-        hipLaunchKernelGGL(k_cover, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, ca);
+        ca.fp.near_clip = b.near_clip;
+        hipLaunchKernelGGL(k_cover, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
         SWR_HIP(c, hipGetLastError());
     }
     {
         ScopedSpan sp(c, ST_RASTER);
         RasterArgs ra;
         ra.fp = frame_params(c);
+        ra.fp.near_clip = b.near_clip;
         ra.recs = c->d_recs.as<TriRec>();
         ra.vout = c->d_vout.as<VOut>();
-        ra.draws = c->d_draws.as<DrawParams>();
+        ra.draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
         ra.tile_start = c->d_tile_start.as<uint32_t>();
         ra.tile_count = c->d_tile_count.as<uint32_t>();
         ra.tile_list = c->d_tile_list.as<uint32_t>();
         ra.color = c->color; ra.depth = c->depth;
         ra.tile_stats = c->d_tile_stats.as<uint32_t>();
-        memcpy(ra.clear_rgba, c->clear_rgba, 16);
-        ra.clear_color_on = c->pend_clear_color ? 1 : 0;
-        ra.clear_depth_on = c->pend_clear_depth ? 1 : 0;
+        memcpy(ra.clear_rgba, b.clear_rgba, 16);
+        ra.clear_color_on = cc ? 1 : 0;
+        ra.clear_depth_on = cd ? 1 : 0;
         ra.blocks_x = (c->tiles_x + 1) / 2;
         ra.blocks_y = (c->band_ty1 - c->band_ty0 + 1) / 2;
-        ra.dbg = c->d_total.as<unsigned long long>() + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
+        ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
+        ra.ctrl = ctrl;
+        const unsigned quads = (unsigned)(ra.blocks_x * ra.blocks_y);
         // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
-        if (immediate) hipLaunchKernelGGL(k_raster, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
-        else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
-        else if (c->raster_variant == 2) hipLaunchKernelGGL(k_raster_b, dim3((unsigned)(ra.blocks_x * ra.blocks_y)), dim3(256), 0, c->stream, ra);
-        else hipLaunchKernelGGL(k_raster_c, dim3((unsigned)(ra.blocks_x * ra.blocks_y) * (4u / SWR_RASTER_WPB)), dim3(64 * SWR_RASTER_WPB), 0, c->stream, ra,
+        if (immediate) hipLaunchKernelGGL(k_raster, dim3(quads), dim3(256), 0, c->stream, ra);
+        else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3(quads), dim3(256), 0, c->stream, ra);
+        else if (c->raster_variant == 2) hipLaunchKernelGGL(k_raster_b, dim3(quads), dim3(256), 0, c->stream, ra);
+        else hipLaunchKernelGGL(k_raster_c, dim3(quads * (4u / SWR_RASTER_WPB)), dim3(64 * SWR_RASTER_WPB), 0, c->stream, ra,
                                 (const uint4*)c->d_masks.as<uint4>(), (const uint16_t*)c->d_pcounts.as<uint16_t>());
         SWR_HIP(c, hipGetLastError());
-        c->pend_clear_color = c->pend_clear_depth = false;
+        cc = cd = false;
     }
     return SWR_OK;
 }
 
-int flush_locked(swr_context* c) {
-    if (c->W <= 0 || c->H <= 0 || band_pixels(c) == 0) {          // Rasterizer.cs:176: silently skip
-        for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
-        c->draws.clear(); c->pend_verts = c->pend_tris = 0;
-        c->pend_clear_color = c->pend_clear_depth = false;
-        return SWR_OK;
-    }
-    if (c->draws.empty()) return run_clear(c);
-
+// launches one batch (clears + draws) on the stream
+int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
+    bool cc = b.clear_color, cd = b.clear_depth;
+    if (b.draws.empty()) return run_clear(c, cc, cd, b.clear_rgba);
     int rc;
-    const size_t nd = c->draws.size();
+    const size_t nd = b.draws.size();
     std::vector<DrawParams> hp(nd);
     std::vector<BlockMap> vblocks, tblocks;
     uint64_t V = 0, T = 0;
+    bool immediate = c->force_immediate;
     for (size_t i = 0; i < nd; ++i) {
-        DrawParams p = c->draws[i].p;
+        DrawParams p = b.draws[i].p;
         p.vert_base = (uint32_t)V; p.tri_base = (uint32_t)T;
         for (uint32_t f = 0; f < p.n_verts; f += 256) vblocks.push_back({ (uint32_t)i, f });
         for (uint32_t f = 0; f < p.n_tris; f += 256) tblocks.push_back({ (uint32_t)i, f });
         V += p.n_verts; T += p.n_tris;
+        immediate = immediate || p.blend == SWR_BLEND_NONE;
         hp[i] = p;
     }
     if (V + 4 * T >= 0xffffffffull || 2 * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
-    if (T == 0) {
-        for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
-        c->draws.clear(); c->pend_verts = c->pend_tris = 0;
-        return run_clear(c);
-    }
+    if (T == 0) return run_clear(c, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
 
-    if ((rc = ensure(c, c->d_draws, nd * sizeof(DrawParams)))) return rc;
-    if ((rc = ensure(c, c->d_vblocks, std::max<size_t>(vblocks.size(), 1) * sizeof(BlockMap)))) return rc;
-    if ((rc = ensure(c, c->d_tblocks, tblocks.size() * sizeof(BlockMap)))) return rc;
+    const size_t off_vb = (nd * sizeof(DrawParams) + 255) & ~(size_t)255;
+    const size_t off_tb = (off_vb + vblocks.size() * sizeof(BlockMap) + 255) & ~(size_t)255;
+    const size_t up_bytes = off_tb + tblocks.size() * sizeof(BlockMap);
+    if ((rc = ensure(c, c->d_upload, up_bytes))) return rc;
     if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
     if ((rc = ensure(c, c->d_recs, (size_t)(2 * T) * sizeof(TriRec)))) return rc;
     if ((rc = ensure(c, c->d_slot_tb, (size_t)(2 * T) * 8))) return rc;
@@ -380,37 +446,101 @@ int flush_locked(swr_context* c) {
         SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
         c->tile_stats_tiles = n_tiles;
     }
+    char* stage = (char*)slot_acquire(c, up_bytes);
+    if (!stage) return fail(c, SWR_ERR_OOM, "hipHostMalloc failed for the upload staging block");
+    memcpy(stage, hp.data(), nd * sizeof(DrawParams));
+    if (!vblocks.empty()) memcpy(stage + off_vb, vblocks.data(), vblocks.size() * sizeof(BlockMap));
+    memcpy(stage + off_tb, tblocks.data(), tblocks.size() * sizeof(BlockMap));
+    SWR_HIP(c, hipMemcpyAsync(c->d_upload.p, stage, up_bytes, hipMemcpyHostToDevice, c->stream));
+    const DrawParams* d_draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
+    const BlockMap* d_vblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_vb);
+    const BlockMap* d_tblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_tb);
 
-    SWR_HIP(c, hipMemcpyAsync(c->d_draws.p, hp.data(), nd * sizeof(DrawParams), hipMemcpyHostToDevice, c->stream));
-    if (!vblocks.empty())
-        SWR_HIP(c, hipMemcpyAsync(c->d_vblocks.p, vblocks.data(), vblocks.size() * sizeof(BlockMap), hipMemcpyHostToDevice, c->stream));
-    SWR_HIP(c, hipMemcpyAsync(c->d_tblocks.p, tblocks.data(), tblocks.size() * sizeof(BlockMap), hipMemcpyHostToDevice, c->stream));
-    // pageable sources: the copies above are staged before returning, so the vectors may die at scope end
-
-    const FrameParams fp = frame_params(c);
+    FrameParams fp = frame_params(c);
+    fp.near_clip = b.near_clip;
     if (!vblocks.empty()) {
         ScopedSpan sp(c, ST_VERTEX);
         hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
-                           c->d_draws.as<DrawParams>(), c->d_vblocks.as<BlockMap>(), c->d_vout.as<VOut>());
+                           d_draws, d_vblocks, c->d_vout.as<VOut>());
         SWR_HIP(c, hipGetLastError());
     }
     {
         ScopedSpan sp(c, ST_SETUP);
         hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, c->stream,
-                           c->d_draws.as<DrawParams>(), c->d_tblocks.as<BlockMap>(), c->d_vout.as<VOut>(),
+                           d_draws, d_tblocks, (const VOut*)c->d_vout.as<VOut>(),
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
-                           c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>());
+                           c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
+                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats);
         SWR_HIP(c, hipGetLastError());
     }
-    bool immediate = c->force_immediate;
-    for (auto& d : c->draws) immediate = immediate || d.p.blend == SWR_BLEND_NONE;
-    rc = bin_and_raster(c, 0, (uint32_t)(2 * T), immediate);
-    for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
-    c->draws.clear(); c->pend_verts = c->pend_tris = 0;
-    c->totals.flushes++;
+    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(2 * T), immediate, mode);
+    slot_submit(c);
     if (rc) return rc;
-    if (c->pend_clear_color || c->pend_clear_depth) return run_clear(c);   // nothing was binned
+    if (cc || cd) return run_clear(c, cc, cd, b.clear_rgba);   // nothing was binned
     return SWR_OK;
+}
+
+void retire_batch(swr_context* c, Batch& b) {
+    for (auto& d : b.draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+    b.draws.clear();
+}
+
+// stream must be idle: looks at the control block, replays what did not fit, retires the in-flight batches
+int validate_locked(swr_context* c) {
+    if (c->inflight.empty()) return SWR_OK;
+    Ctrl h;
+    SWR_HIP(c, hipMemcpy(&h, c->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost));
+    int rc = SWR_OK;
+    if (h.poison) {
+        Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0;
+        SWR_HIP(c, hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice));
+        std::vector<Batch> todo;
+        todo.swap(c->inflight);
+        c->totals.flushes += 0;
+        c->replays++;
+        for (auto& b : todo) {
+            if (!rc && b.seq >= h.first_bad)
+                rc = execute_batch(c, b, MODE_SYNC, b.seq != h.first_bad);   // the first bad batch already counted its triangles
+            retire_batch(c, b);
+        }
+        if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = SWR_ERR_HIP; } }
+        return rc;
+    }
+    for (auto& b : c->inflight) retire_batch(c, b);
+    c->inflight.clear();
+    return SWR_OK;
+}
+
+int flush_locked(swr_context* c) {
+    if (c->W <= 0 || c->H <= 0 || band_pixels(c) == 0) {          // Rasterizer.cs:176: silently skip
+        for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+        c->draws.clear(); c->pend_verts = c->pend_tris = 0;
+        c->pend_clear_color = c->pend_clear_depth = false;
+        return SWR_OK;
+    }
+    if (c->draws.empty() && !c->pend_clear_color && !c->pend_clear_depth) return SWR_OK;
+    Batch b;
+    b.draws.swap(c->draws);
+    b.clear_color = c->pend_clear_color; b.clear_depth = c->pend_clear_depth;
+    memcpy(b.clear_rgba, c->clear_rgba, 16);
+    b.near_clip = c->near_clip;
+    b.seq = c->next_seq++;
+    c->pend_clear_color = c->pend_clear_depth = false;
+    c->pend_verts = c->pend_tris = 0;
+    if (!b.draws.empty()) c->totals.flushes++;
+    // optimistic once an earlier (synchronous) batch has sized the pair buffers
+    const bool optimistic = !c->sync_flush && pair_capacity(c) > 0;
+    int rc = execute_batch(c, b, optimistic ? MODE_ASYNC : MODE_SYNC, 1);
+    if (optimistic && !rc) {
+        c->inflight.push_back(std::move(b));
+        if (c->inflight.size() >= 64) {                            // bound the replay log
+            SWR_HIP(c, hipStreamSynchronize(c->stream));
+            rc = validate_locked(c);
+        }
+    } else {
+        retire_batch(c, b);
+    }
+    return rc;
 }
 
 int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
@@ -507,7 +637,10 @@ int swr_create(int device_id, swr_context** out) {
     }
     c->stream = c->own_stream;
     { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : ((rv && !strcmp(rv, "b")) ? 2 : 0); }
+    { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
+    if (!rc) rc = ensure(c, c->d_ctrl, 64);
+    if (!rc) { Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
     if (!rc) rc = ensure(c, c->d_total, 256 + 1024 * 8);
     if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 1024 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
@@ -521,11 +654,14 @@ void swr_destroy(swr_context* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+    for (auto& b : c->inflight) retire_batch(c, b);
+    c->inflight.clear();
     collect_spans(c);
     free_garbage(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
-    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_draws, &c->d_vblocks, &c->d_tblocks, &c->d_vout, &c->d_recs,
-                       &c->d_slot_tb, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
+    for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
+    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
+                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -607,6 +743,7 @@ int swr_readback(swr_context* c, float* color, float* depth) {
     SWR_ENTER(c);
     int rc = flush_locked(c);
     if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;          // validates optimistic batches BEFORE pixels are observed
     size_t n = band_pixels(c);
     if (n) {
         if (color) SWR_HIP(c, hipMemcpyAsync(color, c->color, n * 16, hipMemcpyDeviceToHost, c->stream));
@@ -619,6 +756,7 @@ int swr_upload(swr_context* c, const float* color, const float* depth) {
     SWR_ENTER(c);
     int rc = flush_locked(c);
     if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     size_t n = band_pixels(c);
     if (n) {
         if (color) SWR_HIP(c, hipMemcpyAsync(c->color, color, n * 16, hipMemcpyHostToDevice, c->stream));
@@ -636,6 +774,7 @@ int swr_get_pixel(swr_context* c, int x, int y, float rgba[4]) {
     rgba[0] = rgba[1] = rgba[2] = rgba[3] = 0.0f;                 // Vector4.Zero out of bounds, MainWindow.cs:397
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemcpyAsync(rgba, c->color + (size_t)(y - band_y0(c)) * c->W + x, 16, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
 }
@@ -644,6 +783,7 @@ int swr_set_pixel(swr_context* c, int x, int y, const float rgba[4]) {
     if (!rgba) return SWR_ERR_INVALID_ARG;
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemcpyAsync(c->color + (size_t)(y - band_y0(c)) * c->W + x, rgba, 16, hipMemcpyHostToDevice, c->stream));
     return sync_locked(c);
 }
@@ -653,6 +793,7 @@ int swr_get_depth(swr_context* c, int x, int y, float* d) {
     *d = SWR_FLOAT_MINVALUE;                                       // MainWindow.cs:425
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemcpyAsync(d, c->depth + (size_t)(y - band_y0(c)) * c->W + x, 4, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
 }
@@ -660,6 +801,7 @@ int swr_set_depth(swr_context* c, int x, int y, float d) {
     SWR_ENTER(c);
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemcpyAsync(c->depth + (size_t)(y - band_y0(c)) * c->W + x, &d, 4, hipMemcpyHostToDevice, c->stream));
     return sync_locked(c);
 }
@@ -795,10 +937,10 @@ int swr_get_stats(swr_context* c, swr_stats* out) {
     swr_stats s = {};
     for (int i = 0; i < 65; ++i) {
         s.triangles_in += host[i].triangles_in; s.triangles_setup += host[i].triangles_setup;
-        s.triangles_clipped += host[i].triangles_clipped;
+        s.triangles_clipped += host[i].triangles_clipped; s.tile_pairs += host[i].tile_pairs;
     }
     s.fragments_tested = frag[0]; s.fragments_shaded = frag[1]; s.fragments_written = frag[2];
-    s.tile_pairs = c->totals.tile_pairs;
+    s.tile_pairs += c->host_tile_pairs;
     s.flushes = c->totals.flushes;
     *out = s;
     return SWR_OK;
@@ -809,7 +951,7 @@ int swr_reset_stats(swr_context* c) {
     int rc = flush_locked(c); if (rc) return rc;
     SWR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream));
     if (c->tile_stats_tiles) SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, c->tile_stats_tiles * 12, c->stream));
-    c->totals = {};
+    c->totals = {}; c->host_tile_pairs = 0;
     return sync_locked(c);
 }
 

@@ -25,6 +25,8 @@ struct BinArgs {
     uint32_t* __restrict__ tile_list;
     uint32_t list_capacity;
     Counters* __restrict__ counters;
+    const Ctrl* __restrict__ ctrl;
+    const unsigned long long* __restrict__ total;
 };
 
 // Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
@@ -109,6 +111,7 @@ __device__ __forceinline__ void bin_wave(const BinArgs& a, bool want, uint32_t t
 // thread per slot; triangles spanning many tiles are spread over the whole wave
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
+    if (FILL && a.ctrl->poison) return;
     const uint32_t slot = a.slot_lo + blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tminx = 0, tminy = 0, nx = 0, ny = 0;
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__
 
 __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
                                                      uint32_t n, const unsigned long long* __restrict__ sums,
-                                                     unsigned long long* __restrict__ total_out) {
+                                                     unsigned long long* __restrict__ total_out,
+                                                     unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
+                                                     Counters* __restrict__ counters, int poison_on_overflow) {
     __shared__ unsigned long long s_part[16];
     __shared__ unsigned long long s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -231,7 +236,18 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
     for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
     const unsigned long long excl = off + wave_off + incl - c;
     if (i < n) start[i] = (uint32_t)min(excl, 0xffffffffull);
-    if (blockIdx.x == gridDim.x - 1 && tid == 1023u) *total_out = excl + c;
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023u) {
+        const unsigned long long total = excl + c;
+        *total_out = total;
+        if (total > capacity) {                     // does not fit: poison this and every later batch
+            if (!poison_on_overflow) return;
+            atomicMin(&ctrl->first_bad, seq);
+            atomicMax(&ctrl->need, total);
+            __hip_atomic_store(&ctrl->poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (poison_on_overflow && !ctrl->poison) {
+            atomicAdd(&counters->tile_pairs, total);        // MODE_SYNC rounds are counted by the host
+        }
+    }
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------
@@ -257,10 +273,10 @@ __device__ __forceinline__ void cmpx_glb(uint32_t* g, uint32_t i, uint32_t p, ui
 __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_list, uint32_t n_tiles,
-                                                   uint32_t* __restrict__ pair_tile) {
+                                                   uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl) {
     __shared__ uint32_t s_keys[SWR_SORT_LDS];
     const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles) return;
+    if (tile >= n_tiles || ctrl->poison) return;
     const uint32_t n = tile_count[tile];
     if (n == 0) return;
     const uint32_t lane = threadIdx.x;

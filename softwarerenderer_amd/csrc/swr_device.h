@@ -68,6 +68,17 @@ struct Counters {           // device-side swr_stats accumulators
     unsigned int pad;
 };
 
+// Optimistic execution control block (one per context, in HBM).  A flush is launched without reading the pair
+// total back: k_scan_apply compares it with the list capacity and, if it does not fit, sets `poison`; every
+// kernel that would touch the pair lists or the framebuffer returns at once while `poison` is set (also for later
+// batches), so the framebuffer stays exactly as it was before the first batch that did not fit.  The host looks
+// at this block at its next synchronisation point, grows the buffers and replays from `first_bad`.
+struct Ctrl {
+    uint32_t poison;
+    uint32_t first_bad;              // sequence number of the first batch that did not fit (atomicMin)
+    unsigned long long need;         // largest pair total seen by a batch that did not fit (atomicMax)
+};
+
 struct FrameParams {
     int width, height;          // full frame
     int tiles_x, tiles_y;       // full frame, in 16x16 tiles

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                TriRec* __restrict__ recs,
                                                unsigned long long* __restrict__ slot_tb,
                                                FrameParams fp,
-                                               Counters* __restrict__ counters /* 64 replicas */) {
+                                               Counters* __restrict__ counters /* 64 replicas */,
+                                               const Ctrl* __restrict__ ctrl, int count_stats) {
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
         atomicAdd(&s_cnt[2], (unsigned)__popcll(clip_mask));
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && count_stats && !ctrl->poison) {
         Counters* c = counters + (blockIdx.x & 63);
         atomicAdd(&c->triangles_in, (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&c->triangles_setup, (unsigned long long)s_cnt[1]);

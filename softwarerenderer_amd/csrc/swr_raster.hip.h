@@ -39,6 +39,7 @@ struct RasterArgs {
     int clear_color_on, clear_depth_on;
     int blocks_x, blocks_y;                // grid of 2x2-tile workgroups over the band
     unsigned long long* dbg;               // SWR_DEBUG_COUNTERS builds only: 8 accumulators
+    const Ctrl* __restrict__ ctrl;         // poison guard (see Ctrl)
 };
 
 // fragment inputs a built-in program may read
@@ -156,6 +157,7 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_raster(RasterArgs a) {
+    if (a.ctrl->poison) return;
     // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
     // contiguous run of tile blocks so that neighbouring tiles' triangle records hit the same L2.
     // Bijective for any grid size; placement only affects speed.
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a) {
 
 // ---- small utility kernels -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_clear(float4* __restrict__ color, float* __restrict__ depth, size_t n,
-                                               float4 rgba, int do_color, int do_depth) {
+                                               float4 rgba, int do_color, int do_depth, const Ctrl* __restrict__ ctrl) {
+    if (ctrl->poison) return;
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
         if (do_color) color[i] = rgba;
         if (do_depth) depth[i] = SWR_FLOAT_MINVALUE;

@@ -47,6 +47,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 }
 
 __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
+    if (a.ctrl->poison) return;
     __shared__ WaveLdsB s_w[4];
 
     const uint32_t nb = gridDim.x, b = blockIdx.x;

@@ -27,18 +27,21 @@ struct CoverArgs {
     const uint32_t* __restrict__ pair_tile;   // band-local tile index per pair
     uint4* __restrict__ masks;                // 2 x uint4 per pair: row r -> bits (r & 1) * 16 .. of word r >> 1
     uint16_t* __restrict__ counts;            // popcount of the mask
-    uint32_t n_pairs;
+    const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
+    const Ctrl* __restrict__ ctrl;
     FrameParams fp;
 };
 
 __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     __shared__ uint32_t s_mask[256][9];       // 8 words per lane (+1 pad: conflict-free row-per-lane access)
+    if (a.ctrl->poison) return;
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n_pairs = (uint32_t)*a.n_pairs;
     uint32_t* mrow = s_mask[threadIdx.x];
 #pragma unroll
     for (int i = 0; i < 8; ++i) mrow[i] = 0u;
     int cnt = 0;
-    if (p < a.n_pairs) {
+    if (p < n_pairs) {
         const uint32_t slot = a.tile_list[p];
         const uint32_t tile = a.pair_tile[p];
         const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = a.fp.band_ty0 + (int)(tile / (uint32_t)a.fp.tiles_x);
@@ -116,6 +119,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 __global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
     __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
+    if (a.ctrl->poison) return;
 
     const uint32_t nb = gridDim.x, b = blockIdx.x;
     const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;

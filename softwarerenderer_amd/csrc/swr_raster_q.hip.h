@@ -33,6 +33,7 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 
 __global__ __launch_bounds__(256) void k_raster_q(RasterArgs a) {
+    if (a.ctrl->poison) return;
     __shared__ WaveLds s_w[4];
 
     const uint32_t nb = gridDim.x, b = blockIdx.x;
