@@ -176,7 +176,9 @@ def main():
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 5),
-                "traffic": None,
+                "traffic": pmc_traffic(args.config, world),
+                "traffic_unit": "GB per launch (PMC FETCH_SIZE raw + WRITE_SIZE; algorithmic = written fragments x 20 B)",
+                "algorithmic_gb_per_launch": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / 1e9, 4),
                 "kernel_ms": round(raster_ms, 4),
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": {k: round(prof[k] / args.steps, 4) for k in
@@ -190,6 +192,19 @@ def main():
     dev.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(config, world):
+    """HBM bytes per k_raster launch from the committed PMC passes of this same command (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside bench.py).  Read side taken raw (lower bound, see the
+    file's provenance note); null when no pass exists for this configuration."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world != 1 or not os.path.exists(path):
+        return None
+    t = json.load(open(path)).get(config)
+    if not t:
+        return None
+    return round((t["fetch_kib_raw"] + t["write_kib"]) * 1024 / 1e9, 4)      # GB per launch
 
 
 def cpu_baseline(scene, renderer, np):

@@ -106,51 +106,68 @@ __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, c
 
 // Rasterizer.Interpolate for the varyings `program` reads, then the fragment program.
 // A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.
+// All vertex-attribute loads are issued together at the top (one memory round trip instead of one per branch:
+// with per-lane vertex pointers each dependent group costs an L2 latency).
+// PIN = true (per-lane vertex pointers): pin the loaded values where they are loaded -- hipcc otherwise sinks each
+// load into the branch that uses it and the fragment pays four or five dependent L2 round trips.
+#define SWR_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+template <bool PIN = false>
 __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, int program, bool interp,
                                                  const VOut* __restrict__ A, const VOut* __restrict__ B,
                                                  const VOut* __restrict__ C, float w0f, float w1f, float w2f) {
+    const float4* __restrict__ pa = reinterpret_cast<const float4*>(A);
+    const float4* __restrict__ pb = reinterpret_cast<const float4*>(B);
+    const float4* __restrict__ pc = reinterpret_cast<const float4*>(C);
     const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
-    if (simple && !interp) return make_float4(A->color[0], A->color[1], A->color[2], A->color[3]);   // :622-627
+    // VOut as four float4: [0] clip  [1] color  [2] uv.xy, wn.xy  [3] wn.z, wpos.xyz
+    float4 a_clip = pa[0], b_clip = pb[0], c_clip = pc[0];
+    float4 a_col = pa[1], b_col = pb[1], c_col = pc[1];
+    float4 a_uvn, b_uvn, c_uvn, a_nz, b_nz, c_nz;
+    if (!simple) { a_uvn = pa[2]; b_uvn = pb[2]; c_uvn = pc[2]; a_nz = pa[3]; b_nz = pb[3]; c_nz = pc[3]; }
+    if (PIN) {
+        SWR_PIN4(a_clip); SWR_PIN4(b_clip); SWR_PIN4(c_clip); SWR_PIN4(a_col); SWR_PIN4(b_col); SWR_PIN4(c_col);
+        if (!simple) { SWR_PIN4(a_uvn); SWR_PIN4(b_uvn); SWR_PIN4(c_uvn); SWR_PIN4(a_nz); SWR_PIN4(b_nz); SWR_PIN4(c_nz); }
+    }
+    if (simple && !interp) return a_col;                                                             // :622-627
 
-    float ra = w0f / A->clip[3];            // :576-578
-    float rb = w1f / B->clip[3];
-    float rc = w2f / C->clip[3];
+    float ra = w0f / a_clip.w;              // :576-578
+    float rb = w1f / b_clip.w;
+    float rc = w2f / c_clip.w;
     float inv_sum = (ra + rb) + rc;         // :579
     float w = 1.0f / inv_sum;               // :582
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
     Frag f;
     if (interp) {
-        f.color = make_float4(SWR_PERSP(A->color[0], B->color[0], C->color[0]), SWR_PERSP(A->color[1], B->color[1], C->color[1]),
-                              SWR_PERSP(A->color[2], B->color[2], C->color[2]), SWR_PERSP(A->color[3], B->color[3], C->color[3]));
+        f.color = make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
+                              SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));
     } else {
-        f.color = make_float4(A->color[0], A->color[1], A->color[2], A->color[3]);
+        f.color = a_col;
     }
     if (simple) return f.color;
 
-    f.clip_z = SWR_PERSP(A->clip[2], B->clip[2], C->clip[2]);
-    f.u = SWR_PERSP(A->uv[0], B->uv[0], C->uv[0]);
-    f.v = SWR_PERSP(A->uv[1], B->uv[1], C->uv[1]);
+    f.clip_z = SWR_PERSP(a_clip.z, b_clip.z, c_clip.z);
+    f.u = SWR_PERSP(a_uvn.x, b_uvn.x, c_uvn.x);
+    f.v = SWR_PERSP(a_uvn.y, b_uvn.y, c_uvn.y);
 #undef SWR_PERSP
     if (interp) {
         float wa = ra * w, wb = rb * w, wc = rc * w;      // :583-585
         // InterpolateData, Vector3 key: weighted sum with the NORMALISED weights, then renormalise (:680-688)
-        float n0 = (A->wn[0] * wa + B->wn[0] * wb) + C->wn[0] * wc;
-        float n1 = (A->wn[1] * wa + B->wn[1] * wb) + C->wn[1] * wc;
-        float n2 = (A->wn[2] * wa + B->wn[2] * wb) + C->wn[2] * wc;
+        float n0 = (a_uvn.z * wa + b_uvn.z * wb) + c_uvn.z * wc;
+        float n1 = (a_uvn.w * wa + b_uvn.w * wb) + c_uvn.w * wc;
+        float n2 = (a_nz.x * wa + b_nz.x * wb) + c_nz.x * wc;
         float len_sq = dot3(n0, n1, n2, n0, n1, n2);
         if (len_sq > 1e-6f) {
             float s = 1.0f / sqrtf(len_sq);
             n0 = n0 * s; n1 = n1 * s; n2 = n2 * s;
         }
         f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
-        if (program == SWR_PROG_PHONG_4POINT) {           // Vector4 key: weighted sum only (:690-693)
-            f.wpos[0] = (A->wpos[0] * wa + B->wpos[0] * wb) + C->wpos[0] * wc;
-            f.wpos[1] = (A->wpos[1] * wa + B->wpos[1] * wb) + C->wpos[1] * wc;
-            f.wpos[2] = (A->wpos[2] * wa + B->wpos[2] * wb) + C->wpos[2] * wc;
-        }
+        // Vector4 key: weighted sum only (:690-693); only PHONG_4POINT reads it
+        f.wpos[0] = (a_nz.y * wa + b_nz.y * wb) + c_nz.y * wc;
+        f.wpos[1] = (a_nz.z * wa + b_nz.z * wb) + c_nz.z * wc;
+        f.wpos[2] = (a_nz.w * wa + b_nz.w * wb) + c_nz.w * wc;
     } else {
-        f.wn[0] = A->wn[0]; f.wn[1] = A->wn[1]; f.wn[2] = A->wn[2];
-        f.wpos[0] = A->wpos[0]; f.wpos[1] = A->wpos[1]; f.wpos[2] = A->wpos[2];
+        f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = a_nz.x;
+        f.wpos[0] = a_nz.y; f.wpos[1] = a_nz.z; f.wpos[2] = a_nz.w;
     }
     if (program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
     return fs_dust2(dp, f);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
 #ifdef SWR_ABLATE_SHADE
                     const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                    const float4 src = shade_fragment(cdp, f_program, (dflags >> 31) != 0u,
+                    const float4 src = shade_fragment<true>(cdp, f_program, (dflags >> 31) != 0u,
                                                       a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
                                                       a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
 #endif

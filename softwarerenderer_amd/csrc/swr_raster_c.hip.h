@@ -88,13 +88,20 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     }
 }
 
+// pairs per batch: 64 fills the wave's lanes in the batch set-up; 32 halves the LDS staging so a fifth wave fits per SIMD
+#ifndef SWR_BATCH
+#define SWR_BATCH 32
+#endif
+#ifndef SWR_RASTER_MINWAVES
+#define SWR_RASTER_MINWAVES 5
+#endif
 struct __attribute__((aligned(16))) WaveLdsC {
     float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
     float z[256];
     uint32_t owner[256];             // chunk duplicate election (0xffffffff when idle)
-    uint32_t mask[64][8];            // batch: coverage masks
-    uint32_t slot[64];               // batch: triangle slot ids
-    uint32_t pre[64 + 4];            // batch: exclusive prefix of covered counts, pre[64] = total
+    uint32_t mask[SWR_BATCH][8];     // batch: coverage masks
+    uint32_t slot[SWR_BATCH];        // batch: triangle slot ids
+    uint32_t pre[SWR_BATCH + 4];     // batch: exclusive prefix of covered counts, pre[SWR_BATCH] = total
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -116,7 +123,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 #ifndef SWR_RASTER_WPB
 #define SWR_RASTER_WPB 1
 #endif
-__global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+__global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
     __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
     if (a.ctrl->poison) return;
@@ -167,9 +174,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, 
     }
     unsigned n_tested = 0, n_shaded = 0, n_written = 0;
 
-    for (uint32_t base = 0; base < n; base += 64u) {
+    for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
         // ---- batch: the next (up to) 64 pairs of this tile; masks and counts staged in LDS ----
-        const bool have = base + (uint32_t)lane < n;
+        const bool have = lane < SWR_BATCH && base + (uint32_t)lane < n;
         const uint32_t pidx = start + base + (uint32_t)lane;
         const uint32_t slot = have ? a.tile_list[pidx] : 0u;
         const int cnt = have ? (int)counts[pidx] : 0;
@@ -178,11 +185,13 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, 
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         if (total == 0) continue;
-        *reinterpret_cast<uint4*>(&L.mask[lane][0]) = m0;
-        *reinterpret_cast<uint4*>(&L.mask[lane][4]) = m1;
-        L.slot[lane] = slot;
-        L.pre[lane] = (uint32_t)(cincl - cnt);
-        if (lane == 0) L.pre[64] = (uint32_t)total;
+        if (lane < SWR_BATCH) {
+            *reinterpret_cast<uint4*>(&L.mask[lane][0]) = m0;
+            *reinterpret_cast<uint4*>(&L.mask[lane][4]) = m1;
+            L.slot[lane] = slot;
+            L.pre[lane] = (uint32_t)(cincl - cnt);
+        }
+        if (lane == 0) L.pre[SWR_BATCH] = (uint32_t)total;
         n_tested += (unsigned)cnt;
 
         // ---- fragment stream of the batch, 64 at a time ----
@@ -190,9 +199,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, 
             const int g = pos + lane;
             const bool valid = g < total;
             // pair of fragment g: largest t with pre[t] <= g  (pre is non-decreasing, pre[0] = 0)
-            int lo = 0, hi = 64;
+            int lo = 0, hi = SWR_BATCH;
 #pragma unroll
-            for (int it = 0; it < 6; ++it) {
+            for (int it = 0; it < (SWR_BATCH == 64 ? 6 : 5); ++it) {
                 const int mid = (lo + hi) >> 1;
                 const bool le = (int)L.pre[mid] <= g;
                 lo = le ? mid : lo;
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB) void k_raster_c(RasterArgs a, 
 #ifdef SWR_ABLATE_SHADE
                     const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                    const float4 src = shade_fragment(cdp, f_program, (dflags >> 31) != 0u,
+                    const float4 src = shade_fragment<true>(cdp, f_program, (dflags >> 31) != 0u,
                                                       a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
                                                       a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
 #endif

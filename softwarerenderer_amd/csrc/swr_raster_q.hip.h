@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_raster_q(RasterArgs a) {
             const uint32_t qi_ = L.qi[lane];                                                                     \
             const uint4 te = L.tbl[qi_ >> 8];                                                                    \
             const int pix = (int)(qi_ & 255u);                                                                   \
-            const float4 src = shade_fragment(cdp, f_program, (te.w >> 31) != 0u, a.vout + te.x, a.vout + te.y,  \
+            const float4 src = shade_fragment<true>(cdp, f_program, (te.w >> 31) != 0u, a.vout + te.x, a.vout + te.y,  \
                                               a.vout + te.z, wv.x, wv.y, wv.z);                                  \
             ++n_shaded;                                                                                          \
             if (src.w > 0.0f) {                                              /* Rasterizer.cs:511 */             \

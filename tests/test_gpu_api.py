@@ -211,3 +211,34 @@ def test_retained_mesh_reuse_and_stats(device):
     assert_frame_parity(c, d, rc, rd, 1, "reuse")
     assert st["triangles_in"] == 3 * rst["triangles_in"] and st["fragments_tested"] == 3 * rst["fragments_tested"]
     assert st["flushes"] == 3 and st["tile_pairs"] > 0
+
+
+def test_optimistic_flush_overflow_is_replayed_exactly(device):
+    """Flushes run without reading the pair total back; a batch that does not fit the pair buffers poisons itself and
+    every later batch on the device, and the host replays them at the next synchronisation point.  Force that path:
+    size the buffers with a tiny scene, then submit two much larger, order-dependent frames back to back."""
+    from oracle.binding import OracleRenderer
+    small = scenes.cfg2(256, 256, 40, seed=50, min_area=10.0, max_area=60.0)
+    big1 = scenes.cfg2(256, 256, 3000, seed=51, min_area=200.0, max_area=9000.0)
+    big2 = scenes.state_scene(256, 256, 2500, seed=52, blend=BlendMode.Additive)
+    big2.clear_color = None; big2.clear_depth = False          # accumulates on top of big1's frame
+    o = OracleRenderer(256, 256)
+    o.render_scene(small); o.reset_stats()
+    o.render_scene(big1)
+    rc, rd = o.render_scene(big2)
+    rst = o.stats()
+
+    r0 = scenes.SceneRenderer(device, small)
+    r0.render()                                                 # synchronous sizing of the pair buffers
+    device.reset_stats()
+    r1 = scenes.SceneRenderer(device, big1, window=r0.window)
+    r2 = scenes.SceneRenderer(device, big2, window=r0.window)
+    r1.submit_frame(); device.flush()                           # optimistic: overflows -> poison
+    r2.submit_frame(); device.flush()                           # skipped on the device while poisoned
+    c, d = r0.window._read()                                    # sync point: validate + replay, then read
+    st = device.stats()
+    for r in (r0, r1, r2):
+        r.close()
+    assert_frame_parity(c, d, rc, rd, 1, "replay")
+    for k in ("triangles_in", "triangles_setup", "fragments_tested", "fragments_shaded", "fragments_written"):
+        assert st[k] == rst[k], (k, st[k], rst[k])
