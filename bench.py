@@ -212,24 +212,31 @@ def cpu_baseline(scene, renderer, np):
     SAME frame: all-core threaded variant (per-tile locks like Rasterizer.cs:478) for `value`, plus one
     serial frame that is also compared word for word with the GPU frame."""
     from oracle.binding import OracleRenderer
-    cores = os.cpu_count() or 1
-    o = OracleRenderer(scene.width, scene.height, threads=cores)
-    o.render_scene(scene)                      # warm-up
-    times = []
+    ncpu = os.cpu_count() or 1
+    # the per-tile-lock structure of the reference stops scaling long before 256 threads on this scene: time a few
+    # thread counts (bounded) and report the fastest, with the thread count actually used as `cores`
+    best = None
     budget_t0 = time.perf_counter()
-    for _ in range(3):
-        o.reset_stats()
-        t0 = time.perf_counter()
-        o.render_scene(scene)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - budget_t0 > 20.0:
+    for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        o = OracleRenderer(scene.width, scene.height, threads=threads)
+        o.render_scene(scene)                      # warm-up
+        times = []
+        for _ in range(3):
+            o.reset_stats()
+            t0 = time.perf_counter()
+            o.render_scene(scene)
+            times.append(time.perf_counter() - t0)
+        st = o.stats()
+        o.close()
+        t = sorted(times)[len(times) // 2]
+        if best is None or t < best[0]:
+            best = (t, threads, st, len(times))
+        if time.perf_counter() - budget_t0 > 15.0:
             break
-    st = o.stats()
-    o.close()
-    t = sorted(times)[len(times) // 2]
+    t, cores, st, nrep = best
     res = {"value": round(st["fragments_tested"] / t / 1e6, 3), "unit": "Mfragments/s", "cores": cores, "kind": "port",
-           "sample": f"the whole {scene.name} frame, median of {len(times)} frames after 1 warm-up, "
-                     f"threaded C restatement of Rasterizer.cs (oracle/swr_oracle.c)",
+           "sample": f"the whole {scene.name} frame, median of {nrep} frames after 1 warm-up, fastest of several thread counts "
+                     f"(host has {ncpu} hardware threads), threaded C restatement of Rasterizer.cs (oracle/swr_oracle.c)",
            "ms_per_frame": round(t * 1e3, 2)}
     # one serial frame = the oracle of record; doubles as a full-size parity check of the GPU frame
     o = OracleRenderer(scene.width, scene.height, threads=1)

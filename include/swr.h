@@ -134,6 +134,9 @@ int  swr_set_depth(swr_context* ctx, int x, int y, float depth);         /* Main
 /* flush, then copy the band into caller memory (either pointer may be NULL); ≙ the host reading
  * ColorBuffer/DepthBuffer in MainWindow.OnRender (MainWindow.cs:226-263) */
 int  swr_readback(swr_context* ctx, float* color_rgba, float* depth);
+/* flush, then copy the colour band as packed RGB floats (12 B per pixel): the Vector4 -> Vector3 flatten of
+ * MainWindow.OnRender (MainWindow.cs:234-240) done on the GPU, ready for glTexSubImage2D(RGB, FLOAT) */
+int  swr_readback_rgb(swr_context* ctx, float* rgb);
 /* upload caller memory into the band (tests: resume from a known framebuffer state) */
 int  swr_upload(swr_context* ctx, const float* color_rgba, const float* depth);
 int  swr_color_device_ptr(swr_context* ctx, void** out);

@@ -752,6 +752,22 @@ int swr_readback(swr_context* c, float* color, float* depth) {
     return sync_locked(c);
 }
 
+int swr_readback_rgb(swr_context* c, float* rgb) {
+    SWR_ENTER(c);
+    if (!rgb) return fail(c, SWR_ERR_INVALID_ARG, "rgb is null");
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    size_t n = band_pixels(c);
+    if (!n) return SWR_OK;
+    if ((rc = ensure(c, c->d_scratch, n * 12))) return rc;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
+    hipLaunchKernelGGL(k_flatten_rgb, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->color, c->d_scratch.as<float>(), n);
+    SWR_HIP(c, hipGetLastError());
+    SWR_HIP(c, hipMemcpyAsync(rgb, c->d_scratch.p, n * 12, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
+}
+
 int swr_upload(swr_context* c, const float* color, const float* depth) {
     SWR_ENTER(c);
     int rc = flush_locked(c);

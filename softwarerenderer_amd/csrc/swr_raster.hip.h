@@ -351,6 +351,14 @@ __global__ __launch_bounds__(256) void k_clear(float4* __restrict__ color, float
     }
 }
 
+// MainWindow.OnRender's Vector4 -> Vector3 flatten (MainWindow.cs:234-240), on the device: RGB float, 12 B per pixel
+__global__ __launch_bounds__(256) void k_flatten_rgb(const float4* __restrict__ color, float* __restrict__ rgb, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        const float4 c = color[i];
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_texture_sample(const uint8_t* __restrict__ tex, int w, int h,
                                                         const float2* __restrict__ uv, int n, float4* __restrict__ out) {
     int i = blockIdx.x * 256 + threadIdx.x;

@@ -277,6 +277,14 @@ class MainWindow:
     def DepthBuffer(self) -> np.ndarray:
         return self._read(False, True)[1]
 
+    def FlatColorBuffer(self) -> np.ndarray:
+        """The Vector3[] `flatColorBuffer` of MainWindow.OnRender (MainWindow.cs:234-240), flattened on the GPU."""
+        _, rows = self.band_pixel_rows()
+        out = np.empty((rows, max(self.RenderWidth, 0), 3), dtype=np.float32)
+        if out.size:
+            self._dev._ck(self._dev._lib.swr_readback_rgb(self._dev._ctx, out.ctypes.data))
+        return out
+
     def Upload(self, color=None, depth=None):
         c = np.ascontiguousarray(color, dtype=np.float32) if color is not None else None
         d = np.ascontiguousarray(depth, dtype=np.float32) if depth is not None else None

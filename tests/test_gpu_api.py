@@ -88,6 +88,15 @@ def test_framebuffer_accessors(device):
     assert dep[0, 0] == 0.125 and tuple(col[23, 39]) == (1, 2, 3, 4) and (dep.ravel()[1:] == MINVAL).all()
 
 
+def test_present_side_rgb_flatten(device):
+    scene = scenes.cfg2(123, 77, 150, seed=19)
+    r = scenes.SceneRenderer(device, scene)
+    c, _ = r.render()
+    rgb = r.window.FlatColorBuffer()
+    r.close()
+    assert rgb.shape == (77, 123, 3) and np.array_equal(rgb.view(np.uint32), c[..., :3].view(np.uint32))
+
+
 def test_zero_size_target_skips_silently_and_tile_locks_validate(device):
     w = MainWindow(device, 0, 0)
     s = scenes.cfg1()
