@@ -64,6 +64,7 @@ struct Batch {
     bool clear_color = false, clear_depth = false;
     float clear_rgba[4] = { 0, 0, 0, 0 };
     float near_clip = 0.1f;
+    bool wireframe = false;                    // Rasterizer.RenderDebugMode == Wireframe for the whole batch
     uint32_t seq = 0;
 };
 
@@ -347,7 +348,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
         cover_items = (uint32_t)total;
     }
-    const bool use_cover = !immediate && c->raster_variant == 0;
+    const int variant = b.wireframe ? 0 : c->raster_variant;      // only k_cover + k_raster_c know DrawLine records
+    const bool use_cover = !immediate && variant == 0;
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
@@ -398,8 +400,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         const unsigned quads = (unsigned)(ra.blocks_x * ra.blocks_y);
         // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
         if (immediate) hipLaunchKernelGGL(k_raster, dim3(quads), dim3(256), 0, c->stream, ra);
-        else if (c->raster_variant == 1) hipLaunchKernelGGL(k_raster_q, dim3(quads), dim3(256), 0, c->stream, ra);
-        else if (c->raster_variant == 2) hipLaunchKernelGGL(k_raster_b, dim3(quads), dim3(256), 0, c->stream, ra);
+        else if (variant == 1) hipLaunchKernelGGL(k_raster_q, dim3(quads), dim3(256), 0, c->stream, ra);
+        else if (variant == 2) hipLaunchKernelGGL(k_raster_b, dim3(quads), dim3(256), 0, c->stream, ra);
         else hipLaunchKernelGGL(k_raster_c, dim3(quads * (4u / SWR_RASTER_WPB)), dim3(64 * SWR_RASTER_WPB), 0, c->stream, ra,
                                 (const uint4*)c->d_masks.as<uint4>(), (const uint16_t*)c->d_pcounts.as<uint16_t>());
         SWR_HIP(c, hipGetLastError());
@@ -427,7 +429,9 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         immediate = immediate || p.blend == SWR_BLEND_NONE;
         hp[i] = p;
     }
-    if (V + 4 * T >= 0xffffffffull || 2 * T >= 0xffffffffull)
+    const uint64_t spt = b.wireframe ? 6 : 2;        // primitive slots per submitted triangle
+    if (b.wireframe) immediate = false;              // DrawLine has no row early-out: always the cover + stream kernels
+    if (V + 4 * T >= 0xffffffffull || spt * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
@@ -437,8 +441,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const size_t up_bytes = off_tb + tblocks.size() * sizeof(BlockMap);
     if ((rc = ensure(c, c->d_upload, up_bytes))) return rc;
     if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
-    if ((rc = ensure(c, c->d_recs, (size_t)(2 * T) * sizeof(TriRec)))) return rc;
-    if ((rc = ensure(c, c->d_slot_tb, (size_t)(2 * T) * 8))) return rc;
+    if ((rc = ensure(c, c->d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
+    if ((rc = ensure(c, c->d_slot_tb, (size_t)(spt * T) * 8))) return rc;
     if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
@@ -470,10 +474,10 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            d_draws, d_tblocks, (const VOut*)c->d_vout.as<VOut>(),
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
-                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats);
+                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0);
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(2 * T), immediate, mode);
+    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), immediate, mode);
     slot_submit(c);
     if (rc) return rc;
     if (cc || cd) return run_clear(c, cc, cd, b.clear_rgba);   // nothing was binned
@@ -524,6 +528,7 @@ int flush_locked(swr_context* c) {
     b.clear_color = c->pend_clear_color; b.clear_depth = c->pend_clear_depth;
     memcpy(b.clear_rgba, c->clear_rgba, 16);
     b.near_clip = c->near_clip;
+    b.wireframe = c->debug_mode == SWR_DEBUG_WIREFRAME;
     b.seq = c->next_seq++;
     c->pend_clear_color = c->pend_clear_depth = false;
     c->pend_verts = c->pend_tris = 0;
@@ -552,13 +557,11 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
         return fail(c, SWR_ERR_INVALID_ARG, "this program needs a uniform block");
     if (cull < 0 || cull > 2 || depth_test < 0 || depth_test > 7 || blend < 0 || blend > 3)
         return fail(c, SWR_ERR_INVALID_ARG, "enum value out of range");
-    if (c->debug_mode == SWR_DEBUG_WIREFRAME)
-        return fail(c, SWR_ERR_UNSUPPORTED, "DebugMode.Wireframe (Rasterizer.DrawLine) is not implemented by the HIP backend yet");
     if (c->W <= 0 || c->H <= 0) return SWR_OK;                      // Rasterizer.cs:176
     const int n_tris = mesh->n_idx / 3;                             // Rasterizer.cs:180
     if (n_tris == 0) return SWR_OK;
     // keep a batch within the 32-bit slot / vertex numbering
-    if (c->pend_tris + (uint64_t)n_tris > (1ull << 28) || c->pend_verts + (uint64_t)mesh->n_verts > (1ull << 28)) {
+    if (c->pend_tris + (uint64_t)n_tris > (1ull << 27) || c->pend_verts + (uint64_t)mesh->n_verts > (1ull << 28)) {
         int rc = flush_locked(c);
         if (rc) return rc;
     }

@@ -44,7 +44,8 @@ struct BinArgs {
 // products (24-bit x <= 29-bit) are exact and the one addition's error is ~2^-29 of delta.  NaN / Inf inputs
 // make every comparison false, i.e. "keep".
 __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy[3], int minX, int maxX, int minY, int maxY,
-                                               int tx, int ty, int width, int height) {
+                                               int tx, int ty, int width, int height, bool is_line) {
+    if (is_line) return true;         // DrawLine edges: keep every tile of the line's bbox (the test below is for triangles)
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
     const int startX = max(minX, x0), endX = min(maxX, min(x0 + SWR_TILE - 1, width - 1));
     const int startY = max(minY, y0), endY = min(maxY, min(y0 + SWR_TILE - 1, height - 1));
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     int tminx = 0, tminy = 0, nx = 0, ny = 0;
     float sx[3] = { 0.f, 0.f, 0.f }, sy[3] = { 0.f, 0.f, 0.f };
     int minX = 0, maxX = -1, minY = 0, maxY = -1;
+    bool is_line = false;
     if (slot < a.slot_hi) {
         unsigned long long tb = a.slot_tb[slot];
         if (tb != SWR_TB_INVALID) {
@@ -135,6 +137,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                 sx[0] = r0.x; sx[1] = r0.y; sx[2] = r0.z; sy[0] = r0.w; sy[1] = r1.x; sy[2] = r1.y;
                 const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
                 minX = (int)(bbx & 0xffffu); maxX = (int)(bbx >> 16); minY = (int)(bby & 0xffffu); maxY = (int)(bby >> 16);
+                is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
             }
         }
     }
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
             int ty = 0, tx = 0;
             if (want) {
                 ty = tminy + i / nx; tx = tminx + i % nx;
-                want = pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height);
+                want = pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height, is_line);
             }
             bin_wave<FILL>(a, want, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
         }
@@ -165,13 +168,14 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
         const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
+        const bool b_line = __shfl((int)is_line, src) != 0;
         for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
             const int i = i0 + lane;
             bool want = i < s_nt;
             int ty = 0, tx = 0;
             if (want) {
                 ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
-                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height);
+                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
             }
             if (want) {
                 const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);

@@ -17,6 +17,9 @@
 #define SWR_TILE 16                      // Rasterizer.cs:53 TileSize -- part of the numerical contract
 #define SWR_FLOAT_MINVALUE (-3.40282347e+38f)   // float.MinValue, MainWindow.cs:425,434
 #define SWR_EPSILON 1e-6f                // Rasterizer.cs:52
+#define SWR_FLAG_INTERP 0x80000000u
+#define SWR_FLAG_LINE   0x40000000u      // record is one DrawLine edge of DebugMode.Wireframe: sx/sy[0..1] = p0, p1
+#define SWR_DRAW_MASK   0x3fffffffu
 
 namespace swr {
 
@@ -42,7 +45,7 @@ struct TriRec {
     uint32_t vref[3];       // index of outputs[0..2] in the VOut array (clip pool follows the VS outputs)
     uint32_t bbox_x;        // minX | maxX << 16   (pixel bbox, already clamped to the frame)
     uint32_t bbox_y;        // minY | maxY << 16
-    uint32_t draw_flags;    // draw index | (outputs[0].Interpolate ? 1u<<31 : 0)
+    uint32_t draw_flags;    // draw index | SWR_FLAG_LINE (wireframe edge) | SWR_FLAG_INTERP (outputs[0].Interpolate)
 };
 static_assert(sizeof(TriRec) == 64, "TriRec must be 64 bytes");
 
@@ -199,6 +202,22 @@ __device__ __forceinline__ float4 blend(float4 s, float4 d, int mode) {
     default:
         return s;
     }
+}
+
+// DrawLine's per-pixel test, Rasterizer.cs:296-313: parameter t of the closest point of segment p0->p1 to the
+// pixel centre (x+0.5, y+0.5) and whether the centre lies within 0.5 px of the segment
+__device__ __forceinline__ bool line_test(float p0x, float p0y, float p1x, float p1y, int x, int y, float& t_out) {
+    const float dx = p1x - p0x, dy = p1y - p0y;                       // :257-258
+    const float len_sq = dx * dx + dy * dy;                          // :259
+    const float px = (float)x + 0.5f - p0x, py = (float)y + 0.5f - p0y;   // :296-297
+    float t = 0.0f;
+    if (len_sq > 0) t = (px * dx + py * dy) / len_sq;                // :300-301
+    t = mathf_max(0.0f, mathf_min(1.0f, t));                         // :303
+    const float cx = p0x + t * dx, cy = p0y + t * dy;                // :305-306
+    const float ddx = ((float)x + 0.5f) - cx, ddy = ((float)y + 0.5f) - cy;
+    const float dist_sq = ddx * ddx + ddy * ddy;                     // :310
+    t_out = t;
+    return dist_sq <= 0.5f * 0.5f;                                   // :312-313
 }
 
 // Texture.Sample, Texture.cs:43-63 -- nearest, wrap; texels RGBA8 row-major

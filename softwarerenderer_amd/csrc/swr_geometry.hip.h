@@ -86,12 +86,14 @@ __device__ __forceinline__ void load_vout(const VOut* __restrict__ src, VOut& v)
 #define SWR_TB_INVALID 0xffffffffffffffffull
 
 // DrawTriangle + RasterizeTriangle prologue for one (possibly clipped) triangle.
-// v0,v1,v2 in submission order; r0,r1,r2 their VOut indices.  Returns true and fills the
-// record when the triangle reaches the tile loop.
-__device__ __forceinline__ bool setup_triangle(const FrameParams& fp, int cull, uint32_t draw,
-                                               const SVert& v0, const SVert& v1, const SVert& v2,
-                                               uint32_t r0, uint32_t r1, uint32_t r2,
-                                               TriRec* __restrict__ rec, unsigned long long* __restrict__ tb) {
+// v0,v1,v2 in submission order; r0,r1,r2 their VOut indices.  Fills rec[0] / tb[0] and returns 1 when the
+// triangle reaches the tile loop.  In DebugMode.Wireframe (Rasterizer.cs:419-425) it emits instead up to three
+// DrawLine records rec[0..2] (edges s0-s1, s1-s2, s2-s0, each with depths[0..1] and outputs[0..1] of the
+// TRIANGLE, as the reference passes them) and returns 0 (the oracle's triangles_setup counts filled triangles only).
+__device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, uint32_t draw,
+                                              const SVert& v0, const SVert& v1, const SVert& v2,
+                                              uint32_t r0, uint32_t r1, uint32_t r2,
+                                              TriRec* __restrict__ rec, unsigned long long* __restrict__ tb, bool wireframe) {
     const int rw = fp.width, rh = fp.height;
     // outputs = { v2, v1, v0 }  (Rasterizer.cs:367)
     const SVert* o[3] = { &v2, &v1, &v0 };
@@ -100,18 +102,44 @@ __device__ __forceinline__ bool setup_triangle(const FrameParams& fp, int cull, 
     for (int i = 0; i < 3; ++i) {
         float invW = 1.0f / o[i]->v.clip[3];                        // :371
         float nx = o[i]->v.clip[0] * invW, ny = o[i]->v.clip[1] * invW, nz = o[i]->v.clip[2] * invW;
-        if (is_nan_or_inf(nx) || is_nan_or_inf(ny) || is_nan_or_inf(nz)) return false;   // :378-380
+        if (is_nan_or_inf(nx) || is_nan_or_inf(ny) || is_nan_or_inf(nz)) return 0;       // :378-380
         sx[i] = (nx * 0.5f + 0.5f) * (float)rw;                     // :383-386
         sy[i] = (1.0f - (ny * 0.5f + 0.5f)) * (float)rh;
         dz[i] = (nz + 1.0f) * 0.5f;                                 // :388
     }
-    if (v0.v.clip[3] == 0 || v1.v.clip[3] == 0 || v2.v.clip[3] == 0) return false;       // :393
+    if (v0.v.clip[3] == 0 || v1.v.clip[3] == 0 || v2.v.clip[3] == 0) return 0;           // :393
     float area = edge_function(sx[0], sy[0], sx[1], sy[1], sx[2], sy[2]);                // :396, :411
-    if (area == 0) return false;
+    if (area == 0) return 0;
     bool front = area < 0;                                                               // :414
-    if ((cull == SWR_CULL_BACK && !front) || (cull == SWR_CULL_FRONT && front)) return false;
-    float inv_area = 1.0f / area;                                                        // :427
+    if ((cull == SWR_CULL_BACK && !front) || (cull == SWR_CULL_FRONT && front)) return 0;
+    const uint32_t flags = draw | (o[0]->interp ? SWR_FLAG_INTERP : 0u);
 
+    if (wireframe) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            const int i0 = e, i1 = (e + 1) % 3;
+            const float p0x = sx[i0], p0y = sy[i0], p1x = sx[i1], p1y = sy[i1];
+            // DrawLine bbox, Rasterizer.cs:242-247: truncating casts of the clamped extremes
+            const int minX = f2i(mathf_max(mathf_min(p0x, p1x), 0.0f));
+            const int maxX = f2i(mathf_min(mathf_max(p0x, p1x), (float)(rw - 1)));
+            const int minY = f2i(mathf_max(mathf_min(p0y, p1y), 0.0f));
+            const int maxY = f2i(mathf_min(mathf_max(p0y, p1y), (float)(rh - 1)));
+            if (minX > maxX || minY > maxY) continue;
+            float4* out = reinterpret_cast<float4*>(rec + e);
+            out[0] = make_float4(p0x, p1x, 0.0f, p0y);
+            out[1] = make_float4(p1y, 0.0f, dz[0], dz[1]);
+            out[2] = make_float4(dz[2], 0.0f, __uint_as_float(r2), __uint_as_float(r1));    // outputs[0], outputs[1]
+            out[3] = make_float4(__uint_as_float(r2),                                        // third weight is 0 on outputs[0]
+                                 __uint_as_float((uint32_t)minX | ((uint32_t)maxX << 16)),
+                                 __uint_as_float((uint32_t)minY | ((uint32_t)maxY << 16)),
+                                 __uint_as_float(flags | SWR_FLAG_LINE));
+            tb[e] = (unsigned long long)(minX / SWR_TILE) | ((unsigned long long)(maxX / SWR_TILE) << 16) |
+                    ((unsigned long long)(minY / SWR_TILE) << 32) | ((unsigned long long)(maxY / SWR_TILE) << 48);
+        }
+        return 0;
+    }
+
+    float inv_area = 1.0f / area;                                                        // :427
     float minXf = mathf_min(mathf_min(sx[0], sx[1]), sx[2]);                             // :432-435
     float maxXf = mathf_max(mathf_max(sx[0], sx[1]), sx[2]);
     float minYf = mathf_min(mathf_min(sy[0], sy[1]), sy[2]);
@@ -120,7 +148,7 @@ __device__ __forceinline__ bool setup_triangle(const FrameParams& fp, int cull, 
     int maxX = min(f2i(ceilf(maxXf)), rw - 1);
     int minY = max(f2i(floorf(minYf)), 0);
     int maxY = min(f2i(ceilf(maxYf)), rh - 1);
-    if (minX > maxX || minY > maxY) return false;                                        // :442
+    if (minX > maxX || minY > maxY) return 0;                                            // :442
 
     float4* out = reinterpret_cast<float4*>(rec);
     out[0] = make_float4(sx[0], sx[1], sx[2], sy[0]);
@@ -129,16 +157,16 @@ __device__ __forceinline__ bool setup_triangle(const FrameParams& fp, int cull, 
     out[3] = make_float4(__uint_as_float(r0),
                          __uint_as_float((uint32_t)minX | ((uint32_t)maxX << 16)),
                          __uint_as_float((uint32_t)minY | ((uint32_t)maxY << 16)),
-                         __uint_as_float(draw | (o[0]->interp ? 0x80000000u : 0u)));
+                         __uint_as_float(flags));
     // tile bbox (Rasterizer.cs:449-452), 16 bits each: tminx | tmaxx<<16 | tminy<<32 | tmaxy<<48
-    *tb = (unsigned long long)(minX / SWR_TILE) | ((unsigned long long)(maxX / SWR_TILE) << 16) |
-          ((unsigned long long)(minY / SWR_TILE) << 32) | ((unsigned long long)(maxY / SWR_TILE) << 48);
-    return true;
+    tb[0] = (unsigned long long)(minX / SWR_TILE) | ((unsigned long long)(maxX / SWR_TILE) << 16) |
+            ((unsigned long long)(minY / SWR_TILE) << 32) | ((unsigned long long)(maxY / SWR_TILE) << 48);
+    return 1;
 }
 
-// One thread per submitted triangle.  Slot 2*t is the triangle itself (or the first fan
-// triangle of its clipped polygon), slot 2*t+1 the second fan triangle; slots keep
-// submission order, which the per-tile lists preserve.
+// One thread per submitted triangle.  Filled mode: slot 2*t is the triangle itself (or the first fan triangle of
+// its clipped polygon), slot 2*t+1 the second fan triangle.  Wireframe: six slots per triangle, three DrawLine
+// edges per fan triangle, in the reference's call order.  Slots keep submission order, which the per-tile lists preserve.
 __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
@@ -148,7 +176,7 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                unsigned long long* __restrict__ slot_tb,
                                                FrameParams fp,
                                                Counters* __restrict__ counters /* 64 replicas */,
-                                               const Ctrl* __restrict__ ctrl, int count_stats) {
+                                               const Ctrl* __restrict__ ctrl, int count_stats, int wireframe) {
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
@@ -157,8 +185,9 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
 
     if (active) {
         const uint32_t gt = dp->tri_base + local;
-        const uint32_t slot = 2u * gt;
-        unsigned long long tb0 = SWR_TB_INVALID, tb1 = SWR_TB_INVALID;
+        const uint32_t per_fan = wireframe ? 3u : 1u;
+        const uint32_t slot = 2u * per_fan * gt;
+        unsigned long long tbs[6] = { SWR_TB_INVALID, SWR_TB_INVALID, SWR_TB_INVALID, SWR_TB_INVALID, SWR_TB_INVALID, SWR_TB_INVALID };
 
         const uint16_t* __restrict__ ip = dp->idx + 3u * local;
         const uint32_t r0 = dp->vert_base + ip[0], r1 = dp->vert_base + ip[1], r2 = dp->vert_base + ip[2];
@@ -202,17 +231,22 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                     const uint32_t pbase = clip_pool_base + 4u * gt;
                     for (int k = 0; k < n; ++k) store_vout(pool + k, poly[k].v);
                     // fan (0, k, k+1), Rasterizer.cs:154-157
-                    if (setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[1], poly[2],
-                                       pbase, pbase + 1, pbase + 2, recs + slot, &tb0)) ++n_setup;
-                    if (n == 4 && setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[2], poly[3],
-                                                 pbase, pbase + 2, pbase + 3, recs + slot + 1, &tb1)) ++n_setup;
+                    n_setup += setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[1], poly[2],
+                                              pbase, pbase + 1, pbase + 2, recs + slot, &tbs[0], wireframe != 0);
+                    if (n == 4) n_setup += setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[2], poly[3],
+                                                          pbase, pbase + 2, pbase + 3, recs + slot + per_fan, &tbs[3], wireframe != 0);
                 }
             } else {
-                if (setup_triangle(fp, dp->cull, bm.draw, v[0], v[1], v[2], r0, r1, r2, recs + slot, &tb0)) ++n_setup;
+                n_setup += setup_triangle(fp, dp->cull, bm.draw, v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], wireframe != 0);
             }
         }
-        slot_tb[slot] = tb0;
-        slot_tb[slot + 1] = tb1;
+        if (wireframe) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) slot_tb[slot + k] = tbs[k];
+        } else {
+            slot_tb[slot] = tbs[0];
+            slot_tb[slot + 1] = tbs[3];
+        }
     }
 
     // block-level counter reduction, then one atomic per counter per block into a replica

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_raster(RasterArgs a) {
         const float d0 = rp->depth[0], d1 = rp->depth[1], d2 = rp->depth[2];
         const float inv_area = rp->inv_area;
         const uint32_t dflags = rp->draw_flags;
-        const DrawParams* __restrict__ dp = a.draws + (dflags & 0x7fffffffu);
+        const DrawParams* __restrict__ dp = a.draws + (dflags & SWR_DRAW_MASK);
         const bool interp = (dflags >> 31) != 0u;
         const int program = dp->program, depth_test = dp->depth_test, blend_mode = dp->blend;
         const VOut* __restrict__ A = a.vout + rp->vref[0];

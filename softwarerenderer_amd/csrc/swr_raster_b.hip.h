@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_raster_b(RasterArgs a) {
             const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
             const bool dup = valid && L.owner[pix] != (uint32_t)lane;
             const uint32_t dflags = __float_as_uint(f3.w);
-            const uint32_t draw = dflags & 0x7fffffffu;
+            const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
             const unsigned long long stop = __ballot(!valid || dup || draw != draw0);
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw

@@ -53,7 +53,20 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
         const int startY = max((int)(bby & 0xffffu), y0), endY = min((int)(bby >> 16), tile_end_y);
-        if (startX <= endX && startY <= endY) {                                                           // :476
+        const bool is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+        if (is_line && startX <= endX && startY <= endY) {
+            // DrawLine, Rasterizer.cs:292-313: every pixel of bbox /\ tile, centre within 0.5 px of the segment
+            for (int y = startY; y <= endY; ++y) {
+                uint32_t rowbits = 0;
+                for (int x = startX; x <= endX; ++x) {
+                    float t;
+                    if (line_test(s0x, s0y, s1x, s1y, x, y, t)) rowbits |= 1u << (x - x0);
+                }
+                const int rr = y - y0;
+                mrow[rr >> 1] |= rowbits << ((rr & 1) * 16);
+                cnt += __popc(rowbits);
+            }
+        } else if (startX <= endX && startY <= endY) {                                                    // :476
             const float a01 = s0y - s1y, b01 = s1x - s0x;                                                 // :445-447
             const float a12 = s1y - s2y, b12 = s2x - s1x;
             const float a20 = s2y - s0y, b20 = s0x - s2x;
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
             // duplicate election: the lowest lane touching a pixel owns it; any other lane on that pixel must wait
             if (valid) atomicMin(&L.owner[pix], (uint32_t)lane);
             const uint32_t dflags = __float_as_uint(f3.w);
-            const uint32_t draw = dflags & 0x7fffffffu;
+            const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
             const bool dup = valid && L.owner[pix] != (uint32_t)lane;
             const unsigned long long stop = __ballot(!valid || dup || draw != draw0);
@@ -259,32 +272,35 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
                 const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
                 const int fsX = max((int)(fbx & 0xffffu), x0), fsY = max((int)(fby & 0xffffu), y0);
                 const int px = x0 + (pix & 15), py = y0 + (pix >> 4);
-                const float a01 = t0y - t1y, b01 = t1x - t0x;
-                const float a12 = t1y - t2y, b12 = t2x - t1x;
-                const float a20 = t2y - t0y, b20 = t0x - t2x;
-                const float fsx = (float)fsX, fsy = (float)fsY;
-                float w0 = a12 * (fsx - t1x) + b12 * (fsy - t1y);                                         // :481-483
-                float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
-                float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
-                const int nrow = py - fsY, ncol = px - fsX;
-#ifndef SWR_ABLATE_CHAIN
-                for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }                       // :532-534
-                for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }                       // :527-529
-#else
-                w0 += (float)nrow * b12 + (float)ncol * a12; w1 += (float)nrow * b20 + (float)ncol * a20; w2 += (float)nrow * b01 + (float)ncol * a01;
-#endif
-                const float w0f = w0 * inv_area, w1f = w1 * inv_area, w2f = w2 * inv_area;               // :498-500
-                const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                         // :502
-                if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505
+                const bool is_line = (dflags & SWR_FLAG_LINE) != 0u;
+                float w0f, w1f, w2f, d;
+                if (is_line) {
+                    // DrawLine fragment, Rasterizer.cs:299-322: weights (1-t, t, 0) on outputs[0], outputs[1], outputs[0]
+                    float t;
+                    (void)line_test(t0x, t0y, t1x, t1y, px, py, t);
+                    w0f = 1.0f - t; w1f = t; w2f = 0.0f;
+                    d = 1.0f / (d0 * (1.0f - t) + d1 * t);                                                // :315
+                } else {
+                    const float a01 = t0y - t1y, b01 = t1x - t0x;
+                    const float a12 = t1y - t2y, b12 = t2x - t1x;
+                    const float a20 = t2y - t0y, b20 = t0x - t2x;
+                    const float fsx = (float)fsX, fsy = (float)fsY;
+                    float w0 = a12 * (fsx - t1x) + b12 * (fsy - t1y);                                     // :481-483
+                    float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
+                    float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
+                    const int nrow = py - fsY, ncol = px - fsX;
+                    for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }                   // :532-534
+                    for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }                   // :527-529
+                    w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
+                    d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
+                }
+                if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505 / :318
                     ++n_shaded;
-#ifdef SWR_ABLATE_SHADE
-                    const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
-#else
-                    const float4 src = shade_fragment<true>(cdp, f_program, (dflags >> 31) != 0u,
-                                                      a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
-                                                      a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509
-#endif
-                    if (src.w > 0.0f) {                                                                    // :511
+                    const float4 src = shade_fragment<true>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                                                            a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
+                                                            a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509 / :321-323
+                    // triangles: W > 0 (:511); lines: W != 0 (:325)
+                    if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
                         const float4 dst = L.col[pix];
                         L.col[pix] = blend(src, dst, f_blend);                                             // :513-515
                         if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = d;                                      // :517-518

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_raster_q(RasterArgs a) {
             const float inv_area = rp->inv_area;
             const uint32_t dflags = rp->draw_flags;
             const uint32_t vr0 = rp->vref[0], vr1 = rp->vref[1], vr2 = rp->vref[2];
-            const uint32_t draw = dflags & 0x7fffffffu;
+            const uint32_t draw = dflags & SWR_DRAW_MASK;
             if (draw != tri_draw) { tri_draw = draw; tri_depth_test = a.draws[draw].depth_test; }
             tri_tbl = -1;
 

@@ -119,13 +119,6 @@ def test_error_behaviour(device):
     q = Shaders.Gouraud()
     with pytest.raises(ValueError):
         Rasterizer.RenderMesh(w, s.draws[0].vertices, s.draws[0].indices, I, I, I, p.VertexShader, q.FragmentShader)
-    Rasterizer.RenderDebugMode = DebugMode.Wireframe
-    try:
-        with pytest.raises(N.SwrError) as e:
-            Rasterizer.RenderMesh(w, s.draws[0].vertices, s.draws[0].indices, I, I, I, p.VertexShader, p.FragmentShader)
-        assert e.value.code == N.SWR_ERR_UNSUPPORTED
-    finally:
-        Rasterizer.RenderDebugMode = DebugMode.None_
     # an index count that is not a multiple of 3 ignores the tail (indices.Length / 3, Rasterizer.cs:180)
     Rasterizer.RenderMesh(w, s.draws[0].vertices, np.array([0, 1, 2, 0, 1], dtype=np.uint16), I, I, I, p.VertexShader, p.FragmentShader,
                           CullMode.None_, DepthTest.Disabled)
