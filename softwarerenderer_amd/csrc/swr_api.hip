@@ -109,7 +109,7 @@ struct swr_context {
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
     unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
 
-    bool profiling = false;
+    int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
     bool force_immediate = false;             // SWR_RASTER=imm: always use k_raster (A/B and tests)
     int raster_variant = 0;                   // SWR_RASTER=q: k_raster_q, b: k_raster_b; default k_cover + k_raster_c
     std::vector<EventSpan> spans;
@@ -212,11 +212,13 @@ hipEvent_t get_event(swr_context* c) {
 }
 struct ScopedSpan {
     swr_context* c; int stage; hipEvent_t a = nullptr, b = nullptr;
+    bool on = false;
     ScopedSpan(swr_context* c_, int st) : c(c_), stage(st) {
-        if (c->profiling) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        on = c->profiling == 1 || (c->profiling == 2 && st == ST_RASTER);
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
     }
     ~ScopedSpan() {
-        if (c->profiling) { (void)hipEventRecord(b, c->stream); c->spans.push_back({ stage, a, b }); }
+        if (on) { (void)hipEventRecord(b, c->stream); c->spans.push_back({ stage, a, b }); }
     }
 };
 
@@ -374,7 +376,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.ctrl = ctrl;
         ca.fp = frame_params(c);
         ca.fp.near_clip = b.near_clip;
-        hipLaunchKernelGGL(k_cover, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
+        if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
+        else hipLaunchKernelGGL(k_cover<false>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -402,8 +405,16 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         if (immediate) hipLaunchKernelGGL(k_raster, dim3(quads), dim3(256), 0, c->stream, ra);
         else if (variant == 1) hipLaunchKernelGGL(k_raster_q, dim3(quads), dim3(256), 0, c->stream, ra);
         else if (variant == 2) hipLaunchKernelGGL(k_raster_b, dim3(quads), dim3(256), 0, c->stream, ra);
-        else hipLaunchKernelGGL(k_raster_c, dim3(quads * (4u / SWR_RASTER_WPB)), dim3(64 * SWR_RASTER_WPB), 0, c->stream, ra,
-                                (const uint4*)c->d_masks.as<uint4>(), (const uint16_t*)c->d_pcounts.as<uint16_t>());
+        else {
+            const dim3 g(quads * (4u / SWR_RASTER_WPB)), t(64 * SWR_RASTER_WPB);
+            const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
+            const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
+            bool phong = false;
+            for (auto& d : b.draws) phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
+            if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);
+            else if (phong) hipLaunchKernelGGL((k_raster_c<false, true>), g, t, 0, c->stream, ra, mk, pc);
+            else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
+        }
         SWR_HIP(c, hipGetLastError());
         cc = cd = false;
     }
@@ -978,7 +989,7 @@ int swr_profile_enable(swr_context* c, int on) {
     SWR_ENTER(c);
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    c->profiling = on != 0;
+    c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
     return SWR_OK;
 }
 int swr_profile_get(swr_context* c, swr_profile* out) {

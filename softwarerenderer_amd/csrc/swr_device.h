@@ -96,11 +96,11 @@ __device__ __forceinline__ bool is_neg_bits(float f) { return (__float_as_uint(f
 __device__ __forceinline__ bool is_nan(float f) { return f != f; }
 __device__ __forceinline__ bool is_nan_or_inf(float f) { return (__float_as_uint(f) & 0x7f800000u) == 0x7f800000u; }
 
-// (int)float, .NET 9 x64: saturating, NaN -> 0
+// (int)float, .NET 9 x64: truncating, saturating, NaN -> 0.  That is exactly v_cvt_i32_f32 on gfx9 (round toward
+// zero, out-of-range and infinities saturate, NaN -> 0); C++ `(int)f` is undefined out of range, so name the instruction.
 __device__ __forceinline__ int f2i(float f) {
-    int r = (int)fminf(fmaxf(f, -2147483648.0f), 2147483520.0f);   // in-range part (fmaxf/fminf drop NaN)
-    r = (f >= 2147483648.0f) ? 2147483647 : r;
-    r = is_nan(f) ? 0 : r;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
     return r;
 }
 // MathF.Min / MathF.Max: NaN-propagating, -0 < +0

@@ -111,7 +111,8 @@ __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, c
 // PIN = true (per-lane vertex pointers): pin the loaded values where they are loaded -- hipcc otherwise sinks each
 // load into the branch that uses it and the fragment pays four or five dependent L2 round trips.
 #define SWR_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
-template <bool PIN = false>
+// PHONG = false compiles the build-defined 4-light program out (batches without such a draw): fewer live registers
+template <bool PIN = false, bool PHONG = true>
 __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, int program, bool interp,
                                                  const VOut* __restrict__ A, const VOut* __restrict__ B,
                                                  const VOut* __restrict__ C, float w0f, float w1f, float w2f) {
@@ -162,14 +163,16 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         }
         f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
         // Vector4 key: weighted sum only (:690-693); only PHONG_4POINT reads it
+        if (PHONG) {
         f.wpos[0] = (a_nz.y * wa + b_nz.y * wb) + c_nz.y * wc;
         f.wpos[1] = (a_nz.z * wa + b_nz.z * wb) + c_nz.z * wc;
         f.wpos[2] = (a_nz.w * wa + b_nz.w * wb) + c_nz.w * wc;
+        }
     } else {
         f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = a_nz.x;
         f.wpos[0] = a_nz.y; f.wpos[1] = a_nz.z; f.wpos[2] = a_nz.w;
     }
-    if (program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
+    if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
     return fs_dust2(dp, f);
 }
 

@@ -32,6 +32,8 @@ struct CoverArgs {
     FrameParams fp;
 };
 
+// LINES: the batch is DebugMode.Wireframe (DrawLine records); compiled out of the filled-triangle instantiation
+template <bool LINES>
 __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     __shared__ uint32_t s_mask[256][9];       // 8 words per lane (+1 pad: conflict-free row-per-lane access)
     if (a.ctrl->poison) return;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
         const int startY = max((int)(bby & 0xffffu), y0), endY = min((int)(bby >> 16), tile_end_y);
-        const bool is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+        const bool is_line = LINES && (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
         if (is_line && startX <= endX && startY <= endY) {
             // DrawLine, Rasterizer.cs:292-313: every pixel of bbox /\ tile, centre within 0.5 px of the segment
             for (int y = startY; y <= endY; ++y) {
@@ -136,6 +138,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 #ifndef SWR_RASTER_WPB
 #define SWR_RASTER_WPB 1
 #endif
+template <bool LINES, bool PHONG>
 __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
     __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
                 const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
                 const int fsX = max((int)(fbx & 0xffffu), x0), fsY = max((int)(fby & 0xffffu), y0);
                 const int px = x0 + (pix & 15), py = y0 + (pix >> 4);
-                const bool is_line = (dflags & SWR_FLAG_LINE) != 0u;
+                const bool is_line = LINES && (dflags & SWR_FLAG_LINE) != 0u;
                 float w0f, w1f, w2f, d;
                 if (is_line) {
                     // DrawLine fragment, Rasterizer.cs:299-322: weights (1-t, t, 0) on outputs[0], outputs[1], outputs[0]
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
                 }
                 if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505 / :318
                     ++n_shaded;
-                    const float4 src = shade_fragment<true>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                    const float4 src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
                                                             a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
                                                             a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509 / :321-323
                     // triangles: W > 0 (:511); lines: W != 0 (:325)

@@ -134,8 +134,9 @@ class Device:
     def reset_stats(self):
         self._ck(self._lib.swr_reset_stats(self._ctx))
 
-    def profile_enable(self, on: bool):
-        self._ck(self._lib.swr_profile_enable(self._ctx, 1 if on else 0))
+    def profile_enable(self, on):
+        """False/0 off, True/1 events around every stage, 2 around the raster kernel only (cheapest)."""
+        self._ck(self._lib.swr_profile_enable(self._ctx, int(on)))
 
     def profile(self) -> dict:
         p = N.Profile()
