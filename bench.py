@@ -87,6 +87,7 @@ def main():
         window.SetBand(*band)
         window.BindFramebuffer(color_t.data_ptr(), depth_t.data_ptr())
         dev.set_stream(torch.cuda.current_stream().cuda_stream)   # order the gather after the frame
+    frame_t = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
     renderer = scenes.SceneRenderer(dev, scene, window=window)
 
     def barrier():
@@ -100,14 +101,16 @@ def main():
         dev.flush()
         if world > 1:
             dev.sync()        # the band must be final (optimistic flushes are validated here) before RCCL reads it
-            multigpu.gather_bands(color_t, H, W, rank, world, dst=0)
+            multigpu.gather_bands(color_t, H, W, rank, world, dst=0, frame=frame_t)
+            torch.cuda.current_stream().synchronize()   # ... and sent before the next frame overwrites it
 
     # Setup (untimed, not part of warmup): the first frame sizes the pair buffers synchronously, and the HIP runtime
     # that torch bundles spends a one-off ~45 ms around its 16th submission (measured: tools/host_timing2.py) growing
     # internal pools.  Prime past both so that the W warmup + K timed steps see the steady state.
     t_prime = time.perf_counter()
     n_prime = 0
-    while n_prime < args.prime or (time.perf_counter() - t_prime < 0.2 and n_prime < 10 * args.prime):
+    # (the count must be the same on every rank: only a single process may extend it by wall time)
+    while n_prime < args.prime or (world == 1 and time.perf_counter() - t_prime < 0.2 and n_prime < 10 * args.prime):
         step()
         dev.sync()
         n_prime += 1

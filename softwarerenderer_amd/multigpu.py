@@ -48,25 +48,34 @@ def max_band_rows(height: int, world_size: int) -> int:
     return max(band_pixel_rows(height, b)[1] for b in band_partition(height, world_size))
 
 
-def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None):
+def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None):
     """Gather the per-rank colour bands (torch tensors of shape (max_band_rows, width, C), rows beyond a
     band's own count are padding) to `dst`; returns the assembled (height, width, C) frame there, else None.
-    Works on any backend (nccl == RCCL on ROCm; gloo on CPU for the tests)."""
+    `frame` (optional, dst only) is a preallocated output.  When every band has the same number of pixel rows
+    the receive buffers ARE row blocks of the frame (no assembly copy).  Works on any backend
+    (nccl == RCCL on ROCm; gloo on CPU for the tests)."""
     import torch
     import torch.distributed as dist
     if world_size == 1:
         return local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
+    bands = band_partition(height, world_size)
+    rows = [band_pixel_rows(height, b) for b in bands]
     bufs = None
+    uniform = all(r[1] == local_band.shape[0] for r in rows)
     if rank == dst:
-        bufs = [torch.empty_like(local_band) for _ in range(world_size)]
+        if frame is None:
+            frame = torch.empty((height, width) + tuple(local_band.shape[2:]), dtype=local_band.dtype, device=local_band.device)
+        if uniform:
+            bufs = [frame[y0:y0 + n] for (y0, n) in rows]          # contiguous row blocks: receive in place
+        else:
+            bufs = [torch.empty_like(local_band) for _ in range(world_size)]
     dist.gather(local_band, gather_list=bufs, dst=dst, group=group)
     if rank != dst:
         return None
-    frame = torch.empty((height, width) + tuple(local_band.shape[2:]), dtype=local_band.dtype, device=local_band.device)
-    for r, band in enumerate(band_partition(height, world_size)):
-        y0, rows = band_pixel_rows(height, band)
-        if rows:
-            frame[y0:y0 + rows] = bufs[r][:rows]
+    if not uniform:
+        for r, (y0, n) in enumerate(rows):
+            if n:
+                frame[y0:y0 + n] = bufs[r][:n]
     return frame
 
 

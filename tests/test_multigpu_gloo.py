@@ -42,7 +42,7 @@ def _worker(rank, world, port, height, width, ok):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,height,width", [(2, 100, 37), (2, 64, 16), (3, 333, 20)])
+@pytest.mark.parametrize("world,height,width", [(2, 100, 37), (2, 64, 16), (3, 333, 20), (2, 128, 24), (4, 256, 8)])
 def test_band_gather_reassembles_the_frame(world, height, width):
     ok = mp.get_context("spawn").Array("i", [0])
     mp.spawn(_worker, args=(world, _free_port(), height, width, ok), nprocs=world, join=True)
