@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--prime", type=int, default=32, help="untimed setup frames before warmup (runtime/buffer initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fake-world", type=int, default=0,
+                    help="self-test of the N>1 code path in ONE process: act as rank 0 of N, collectives stubbed (numbers are meaningless)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not record hipEvents around kernels in the timed region")
     args = ap.parse_args()
 
@@ -64,10 +66,22 @@ def main():
 
     import torch                      # plumbing: device memory for the bands, streams, RCCL
     import torch.distributed as dist
+    if args.fake_world > 1 and world == 1:
+        class _FakeDist:                       # rank 0 of N without peers: exercises bands, double buffering, bookkeeping
+            class ReduceOp: SUM = 0; MAX = 1
+            def barrier(self): pass
+            def all_reduce(self, t, op=None): pass
+            def gather(self, t, gather_list=None, dst=0, group=None):
+                if gather_list is not None:
+                    gather_list[0].copy_(t[:gather_list[0].shape[0]])
+            def destroy_process_group(self): pass
+        dist = _FakeDist()
+        world = args.fake_world
+        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 and not args.fake_world:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -79,30 +93,48 @@ def main():
     dev = Device(local_rank)
     window = MainWindow(dev, W, H)
     color_t = depth_t = None
+    overlap = world > 1 and os.environ.get("SWR_BENCH_OVERLAP", "1") != "0"
     if world > 1:
         band = multigpu.band_partition(H, world)[rank]
         rows = multigpu.max_band_rows(H, world)
-        color_t = torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda")
-        depth_t = torch.zeros((rows, W), dtype=torch.float32, device="cuda")
+        # two band buffers: the colour gather of frame i (RCCL, xGMI) overlaps the rendering of frame i+1
+        color_t = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
+        depth_t = [torch.zeros((rows, W), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
         window.SetBand(*band)
-        window.BindFramebuffer(color_t.data_ptr(), depth_t.data_ptr())
-        dev.set_stream(torch.cuda.current_stream().cuda_stream)   # order the gather after the frame
+        window.BindFramebuffer(color_t[0].data_ptr(), depth_t[0].data_ptr())
     frame_t = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
     renderer = scenes.SceneRenderer(dev, scene, window=window)
+    state = {"i": 0, "pending": None}
+
+    def wait_gather():
+        if state["pending"] is not None:
+            torch.cuda.current_stream().synchronize()      # the previous frame's bands have arrived / been sent
+            state["pending"] = None
 
     def barrier():
+        wait_gather()
         if world > 1:
             dist.barrier()
         dev.sync()
         torch.cuda.synchronize()
 
     def step():
+        if world == 1:
+            renderer.submit_frame()
+            dev.flush()
+            return
+        k = state["i"] % len(color_t)
+        state["i"] += 1
+        if len(color_t) > 1:
+            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
         renderer.submit_frame()
-        dev.flush()
-        if world > 1:
-            dev.sync()        # the band must be final (optimistic flushes are validated here) before RCCL reads it
-            multigpu.gather_bands(color_t, H, W, rank, world, dst=0, frame=frame_t)
-            torch.cuda.current_stream().synchronize()   # ... and sent before the next frame overwrites it
+        dev.sync()            # the band must be final (optimistic flushes are validated here) before RCCL reads it
+        wait_gather()         # one gather in flight at a time (it fills the same frame on rank 0)
+        multigpu.gather_bands(color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+        if overlap:
+            state["pending"] = k          # completes while the next frame renders into the other buffer
+        else:
+            torch.cuda.current_stream().synchronize()
 
     # Setup (untimed, not part of warmup): the first frame sizes the pair buffers synchronously, and the HIP runtime
     # that torch bundles spends a one-off ~45 ms around its 16th submission (measured: tools/host_timing2.py) growing
@@ -171,7 +203,8 @@ def main():
                                    f"{'2048^2 RGBA8 nearest texture, ' if scene.textures else ''}"
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
-                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL colour gather to rank 0"},
+                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL colour gather to rank 0"
+                                      + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")},
             "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
             "fragments_tested_per_frame": int(frags_tested),
             "fragments_written_per_frame": int(frags_written),
@@ -183,7 +216,7 @@ def main():
             raster_ms = prof["raster_ms"] / prof["raster_launches"]
             written_local = st["fragments_written"] / args.steps
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
-            frame_bytes = (W * H if world == 1 else color_t.shape[0] * W) * 20.0
+            frame_bytes = (W * H if world == 1 else color_t[0].shape[0] * W) * 20.0
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_raster",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -103,6 +103,7 @@ struct swr_context {
     FrameSlot slots[SWR_SLOTS];
     uint32_t slot_next = 0;
     DevBuf d_pair_tile, d_masks, d_pcounts, d_ctrl;
+    uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
@@ -503,11 +504,12 @@ void retire_batch(swr_context* c, Batch& b) {
 // stream must be idle: looks at the control block, replays what did not fit, retires the in-flight batches
 int validate_locked(swr_context* c) {
     if (c->inflight.empty()) return SWR_OK;
-    Ctrl h;
-    SWR_HIP(c, hipMemcpy(&h, c->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost));
     int rc = SWR_OK;
-    if (h.poison) {
-        Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0;
+    if (*(volatile uint32_t*)c->host_poison) {          // set by k_scan_apply together with Ctrl::poison (stream is idle here)
+        Ctrl h;
+        SWR_HIP(c, hipMemcpy(&h, c->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost));
+        *c->host_poison = 0;
+        Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison;
         SWR_HIP(c, hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice));
         std::vector<Batch> todo;
         todo.swap(c->inflight);
@@ -654,7 +656,8 @@ int swr_create(int device_id, swr_context** out) {
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_ctrl, 64);
-    if (!rc) { Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
+    if (!rc && hipHostMalloc((void**)&c->host_poison, 64, hipHostMallocDefault) != hipSuccess) rc = SWR_ERR_OOM;
+    if (!rc) { *c->host_poison = 0; Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
     if (!rc) rc = ensure(c, c->d_total, 256 + 1024 * 8);
     if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 1024 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
@@ -674,6 +677,7 @@ void swr_destroy(swr_context* c) {
     free_garbage(c);
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
+    if (c->host_poison) (void)hipHostFree(c->host_poison);
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
                        &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
                        &c->d_counters, &c->d_total, &c->d_scratch };

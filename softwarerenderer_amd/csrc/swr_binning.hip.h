@@ -248,6 +248,7 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
             atomicMin(&ctrl->first_bad, seq);
             atomicMax(&ctrl->need, total);
             __hip_atomic_store(&ctrl->poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ctrl->host_flag) __hip_atomic_store(ctrl->host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         } else if (poison_on_overflow && !ctrl->poison) {
             atomicAdd(&counters->tile_pairs, total);        // MODE_SYNC rounds are counted by the host
         }

@@ -80,6 +80,7 @@ struct Ctrl {
     uint32_t poison;
     uint32_t first_bad;              // sequence number of the first batch that did not fit (atomicMin)
     unsigned long long need;         // largest pair total seen by a batch that did not fit (atomicMax)
+    uint32_t* host_flag;             // pinned host word, set to 1 together with `poison`: the host polls it without a copy
 };
 
 struct FrameParams {

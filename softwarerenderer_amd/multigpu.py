@@ -48,14 +48,15 @@ def max_band_rows(height: int, world_size: int) -> int:
     return max(band_pixel_rows(height, b)[1] for b in band_partition(height, world_size))
 
 
-def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None):
+def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None, dist=None):
     """Gather the per-rank colour bands (torch tensors of shape (max_band_rows, width, C), rows beyond a
     band's own count are padding) to `dst`; returns the assembled (height, width, C) frame there, else None.
     `frame` (optional, dst only) is a preallocated output.  When every band has the same number of pixel rows
     the receive buffers ARE row blocks of the frame (no assembly copy).  Works on any backend
     (nccl == RCCL on ROCm; gloo on CPU for the tests)."""
     import torch
-    import torch.distributed as dist
+    if dist is None:
+        import torch.distributed as dist
     if world_size == 1:
         return local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
     bands = band_partition(height, world_size)

@@ -288,6 +288,21 @@ class SceneRenderer:
             tex = self.textures[d.texture] if d.texture is not None else None
             self.programs.append(ShaderProgram(d.program, d.uniforms, tex))
             self.meshes.append(Mesh(device, d.vertices, d.indices) if retained else None)
+        self._calls = None
+
+    def _prepare(self):
+        """ctypes arguments of every RenderMesh call, converted once (the per-frame host cost is then ~16 FFI calls)."""
+        ctx = self.dev._ctx
+        fp = C.POINTER(C.c_float)
+        calls = []
+        for d, prog, mesh in zip(self.scene.draws, self.programs, self.meshes):
+            if mesh is None:
+                return None
+            mats = [np.ascontiguousarray(np.asarray(m, dtype=np.float32).reshape(-1)) for m in (d.model, d.view, d.projection)]
+            calls.append((mats, (ctx, mesh._h, mats[0].ctypes.data_as(fp), mats[1].ctypes.data_as(fp), mats[2].ctypes.data_as(fp),
+                                 int(prog.program), C.byref(prog.uniforms), prog.texture._h if prog.texture is not None else None,
+                                 int(d.cull), int(d.depth_test), int(d.blend))))
+        return calls
 
     def submit_frame(self):
         """One frame = RenderScene of Renderer.cs:404-419: clears, then one RenderMesh per mesh (not flushed)."""
@@ -297,6 +312,17 @@ class SceneRenderer:
             w.ClearDepthBuffer()
         if s.clear_color is not None:
             w.ClearColorBuffer(s.clear_color)
+        if self._calls is None:
+            self._calls = self._prepare() or False
+        if self._calls:
+            dev = self.dev
+            dev._ck(dev._lib.swr_set_state(dev._ctx, float(Rasterizer.NearClip), float(Rasterizer.FarClip), int(Rasterizer.RenderDebugMode)))
+            render = dev._lib.swr_render_mesh
+            for _, args in self._calls:
+                rc = render(*args)
+                if rc:
+                    dev._ck(rc)
+            return
         for d, prog, mesh in zip(s.draws, self.programs, self.meshes):
             Rasterizer.RenderMesh(w, mesh if mesh is not None else d.vertices, d.indices, d.model, d.view, d.projection,
                                   prog.VertexShader, prog.FragmentShader, d.cull, d.depth_test, d.blend)
