@@ -148,3 +148,35 @@ def test_wireframe_debug_mode(device, make):
     for k in ("triangles_in", "triangles_setup", "triangles_clipped", "fragments_tested", "fragments_shaded", "fragments_written"):
         assert st[k] == rst[k], (k, st[k], rst[k])
     assert rst["fragments_written"] > 0 or scene.name == "degenerate"
+
+
+def _random_scene(seed):
+    """A random small frame: random size (incl. non-multiples of 16 and tiny targets), a mix of tiny / huge / sliver /
+    behind-camera / off-screen triangles, random matrices and a random state vector."""
+    import softwarerenderer_amd.hostmath as hm
+    rng = np.random.default_rng(seed)
+    W, H = int(rng.integers(1, 220)), int(rng.integers(1, 160))
+    n = int(rng.integers(1, 500))
+    proj = scenes._perspective(W, H, fov_deg=float(rng.uniform(40, 110)))
+    kind = rng.integers(0, 5, n)
+    c = np.stack([rng.uniform(-6, 6, n), rng.uniform(-4, 4, n), rng.uniform(-12.0, 1.0, n)], axis=1)
+    size = np.where(kind == 0, 0.05, np.where(kind == 1, 0.5, np.where(kind == 2, 3.0, np.where(kind == 3, 12.0, 1.0))))
+    pos = c[:, None, :] + rng.normal(size=(n, 3, 3)) * size[:, None, None]
+    sliver = kind == 4
+    pos[sliver, 2, :] = pos[sliver, 0, :] * 0.5 + pos[sliver, 1, :] * 0.5 + rng.normal(size=(int(sliver.sum()), 3)) * 1e-3
+    col = np.concatenate([rng.uniform(0, 1, (3 * n, 3)), rng.choice([0.0, 0.3, 1.0], size=(3 * n, 1), p=[0.1, 0.3, 0.6])], axis=1)
+    nrm = rng.normal(size=(3 * n, 3)); nrm[rng.uniform(size=3 * n) < 0.02] = 0.0          # a few zero normals -> NaN WorldNormal
+    v = scenes.make_vertices(pos.reshape(-1, 3), uv=rng.uniform(-3, 4, (3 * n, 2)), normal=nrm, color=col)
+    model = hm.multiply(hm.create_scale(float(rng.uniform(0.5, 1.5))), hm.create_rotation_y(float(rng.uniform(-0.5, 0.5))))
+    view = hm.create_look_at((float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)), 2.0), (0.0, 0.0, -5.0), (0.0, 1.0, 0.0))
+    program = Program(int(rng.integers(0, 3)))
+    d = scenes.Draw(v, np.arange(3 * n, dtype=np.uint16), model, view, proj, program=program, uniforms=scenes.default_uniforms(),
+                    texture=0 if rng.uniform() < 0.7 else None, cull=CullMode(int(rng.integers(0, 3))),
+                    depth_test=DepthTest(int(rng.integers(0, 8))), blend=BlendMode(int(rng.integers(0, 4))))
+    return scenes.Scene(f"random{seed}", W, H, [d], textures=[scenes.random_texture(int(rng.integers(1, 40)), seed, alpha=None)],
+                        near_clip=float(rng.choice([0.1, 0.5, 0.01])))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_randomised_scenes(device, seed):
+    run_both(device, _random_scene(1000 + seed))
