@@ -35,13 +35,13 @@ struct CoverArgs {
 // LINES: the batch is DebugMode.Wireframe (DrawLine records); compiled out of the filled-triangle instantiation
 template <bool LINES>
 __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
-    __shared__ uint32_t s_mask[256][9];       // 8 words per lane (+1 pad: conflict-free row-per-lane access)
+    __shared__ uint16_t s_rows[256][18];      // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
     if (a.ctrl->poison) return;
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
-    uint32_t* mrow = s_mask[threadIdx.x];
+    uint16_t* mrow16 = s_rows[threadIdx.x];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mrow[i] = 0u;
+    for (int i = 0; i < 16; ++i) mrow16[i] = 0;
     int cnt = 0;
     if (p < n_pairs) {
         const uint32_t slot = a.tile_list[p];
@@ -64,9 +64,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
                     float t;
                     if (line_test(s0x, s0y, s1x, s1y, x, y, t)) rowbits |= 1u << (x - x0);
                 }
-                const int rr = y - y0;
-                mrow[rr >> 1] |= rowbits << ((rr & 1) * 16);
-                cnt += __popc(rowbits);
+                mrow16[y - y0] = (uint16_t)rowbits;
             }
         } else if (startX <= endX && startY <= endY) {                                                    // :476
             const float a01 = s0y - s1y, b01 = s1x - s0x;                                                 // :445-447
@@ -76,29 +74,56 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
             float w0r = a12 * (fsx - s1x) + b12 * (fsy - s1y);                                            // :481-483
             float w1r = a20 * (fsx - s2x) + b20 * (fsy - s2y);
             float w2r = a01 * (fsx - s0x) + b01 * (fsy - s0y);
-            float w0 = w0r, w1 = w1r, w2 = w2r;
-            const int area = (endX - startX + 1) * (endY - startY + 1);
-            int x = startX, y = startY;
-            uint32_t rowbits = 0;
-            for (int it = 0; it < area; ++it) {
-                const bool inside = (w0 >= 0 && w1 >= 0 && w2 >= 0) || (w0 <= 0 && w1 <= 0 && w2 <= 0);  // :493-494
-                rowbits |= inside ? (1u << (x - x0)) : 0u;
-                if (x == endX) {                                                                          // :532-534, :487-489
-                    const int rr = y - y0;
-                    mrow[rr >> 1] |= rowbits << ((rr & 1) * 16);
-                    cnt += __popc(rowbits);
-                    rowbits = 0;
-                    w0r += b12; w1r += b20; w2r += b01;
-                    w0 = w0r; w1 = w1r; w2 = w2r;
-                    x = startX; ++y;
-                } else {                                                                                  // :527-529
-                    w0 += a12; w1 += a20; w2 += a01;
-                    ++x;
+            // Fast path when nothing in the chain can be NaN/Inf (all nine inputs finite and < 1e30: at most 30 adds
+            // cannot overflow): for finite values "all >= 0" <=> min3 >= 0 and "all <= 0" <=> max3 <= 0 (signed zeros
+            // satisfy both, exactly like the reference's comparisons), and the loops are plain row / column nests.
+            // Anything else (overflowed screen coordinates) takes the literal six-comparison walk below.
+            const float lim = 1.0e30f;
+            const bool fast = fabsf(a12) < lim && fabsf(a20) < lim && fabsf(a01) < lim && fabsf(b12) < lim && fabsf(b20) < lim &&
+                              fabsf(b01) < lim && fabsf(w0r) < lim && fabsf(w1r) < lim && fabsf(w2r) < lim;
+            if (fast) {
+                const uint32_t bit0 = 1u << (startX - x0);
+                for (int y = startY; y <= endY; ++y) {
+                    float w0 = w0r, w1 = w1r, w2 = w2r;
+                    uint32_t rowbits = 0, bit = bit0;
+                    for (int x = startX; x <= endX; ++x) {
+                        const bool inside = fminf(fminf(w0, w1), w2) >= 0.0f || fmaxf(fmaxf(w0, w1), w2) <= 0.0f;   // :493-494
+                        rowbits |= inside ? bit : 0u;
+                        bit <<= 1;
+                        w0 += a12; w1 += a20; w2 += a01;                                                  // :527-529
+                    }
+                    mrow16[y - y0] = (uint16_t)rowbits;
+                    w0r += b12; w1r += b20; w2r += b01;                                                   // :532-534
+                }
+            } else {
+                float w0 = w0r, w1 = w1r, w2 = w2r;
+                const int area = (endX - startX + 1) * (endY - startY + 1);
+                int x = startX, y = startY;
+                uint32_t rowbits = 0;
+                for (int it = 0; it < area; ++it) {
+                    const bool inside = (w0 >= 0 && w1 >= 0 && w2 >= 0) || (w0 <= 0 && w1 <= 0 && w2 <= 0);  // :493-494
+                    rowbits |= inside ? (1u << (x - x0)) : 0u;
+                    if (x == endX) {                                                                          // :532-534, :487-489
+                        mrow16[y - y0] = (uint16_t)rowbits;
+                        rowbits = 0;
+                        w0r += b12; w1r += b20; w2r += b01;
+                        w0 = w0r; w1 = w1r; w2 = w2r;
+                        x = startX; ++y;
+                    } else {                                                                                  // :527-529
+                        w0 += a12; w1 += a20; w2 += a01;
+                        ++x;
+                    }
                 }
             }
         }
-        a.masks[2 * (size_t)p] = make_uint4(mrow[0], mrow[1], mrow[2], mrow[3]);
-        a.masks[2 * (size_t)p + 1] = make_uint4(mrow[4], mrow[5], mrow[6], mrow[7]);
+        uint32_t mw[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {          // word i = rows 2i (low half) and 2i+1 (high half)
+            mw[i] = (uint32_t)mrow16[2 * i] | ((uint32_t)mrow16[2 * i + 1] << 16);
+            cnt += __popc(mw[i]);
+        }
+        a.masks[2 * (size_t)p] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+        a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
         a.counts[p] = (uint16_t)cnt;
     }
 }
@@ -238,20 +263,24 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
             const uint4 mb = *reinterpret_cast<const uint4*>(&L.mask[t][4]);
             int pix = 0;
             {
-                const uint32_t wds[8] = { ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w };
-                uint32_t wsel = wds[0];
-                int wi = 0;
-                bool found = false;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = __popc(wds[i]);
-                    const bool here = !found && k < c;
-                    wsel = here ? wds[i] : wsel;
-                    wi = here ? i : wi;
-                    found = found || here;
-                    k -= (!found) ? c : 0;
-                }
-                pix = wi * 32 + kth_set_bit32(wsel, valid && found ? k : 0);
+                // k-th set bit of the 256-bit mask: 3-level selection over the 8 words, then inside the word
+                const int c0 = __popc(ma.x), c1 = __popc(ma.y), c2 = __popc(ma.z), c3 = __popc(ma.w);
+                const int c4 = __popc(mb.x), c5 = __popc(mb.y), c6 = __popc(mb.z);
+                const int s01 = c0 + c1, s23 = c2 + c3, s45 = c4 + c5, s0123 = s01 + s23;
+                const bool up1 = k >= s0123;
+                k -= up1 ? s0123 : 0;
+                const uint32_t a0 = up1 ? mb.x : ma.x, a1 = up1 ? mb.y : ma.y, a2 = up1 ? mb.z : ma.z, a3 = up1 ? mb.w : ma.w;
+                const int sa = up1 ? s45 : s01, ca0 = up1 ? c4 : c0, ca2 = up1 ? c6 : c2;
+                const bool up2 = k >= sa;
+                k -= up2 ? sa : 0;
+                const uint32_t b0 = up2 ? a2 : a0, b1 = up2 ? a3 : a1;
+                const int cb0 = up2 ? ca2 : ca0;
+                const bool up3 = k >= cb0;
+                k -= up3 ? cb0 : 0;
+                const uint32_t wsel = up3 ? b1 : b0;
+                const int wi = (up1 ? 4 : 0) + (up2 ? 2 : 0) + (up3 ? 1 : 0);
+                const bool okk = valid && k < __popc(wsel);          // always true for a valid fragment
+                pix = wi * 32 + kth_set_bit32(wsel, okk ? k : 0);
             }
 #ifdef SWR_ABLATE_KTH
             asm volatile("" :: "v"(pix)); pix = (g * 7) & 255;
