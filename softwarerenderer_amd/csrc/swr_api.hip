@@ -303,6 +303,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
     ba.recs = c->d_recs.as<TriRec>();
     ba.slot_lo = lo; ba.slot_hi = hi;
+    ba.spt = b.wireframe ? 6u : 2u;
     ba.width = c->W; ba.height = c->H;
     ba.tiles_x = c->tiles_x; ba.band_ty0 = c->band_ty0; ba.band_ty1 = c->band_ty1;
     ba.tile_count = c->d_tile_count.as<uint32_t>();
@@ -312,7 +313,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     ba.counters = c->d_counters.as<Counters>();
     ba.ctrl = ctrl;
     ba.total = d_total;
-    const uint32_t bin_blocks = (hi - lo + 255u) / 256u;
+    const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;
+    const uint32_t bin_blocks = (bin_threads + 255u) / 256u;
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));

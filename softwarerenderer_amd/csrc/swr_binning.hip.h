@@ -17,6 +17,8 @@ struct BinArgs {
     const unsigned long long* __restrict__ slot_tb;
     const TriRec* __restrict__ recs;
     uint32_t slot_lo, slot_hi;           // slots [lo, hi) are binned in this round
+    uint32_t spt;                        // slots per thread = slots per triangle (2 filled, 6 wireframe): the odd
+                                         // fan slots are almost always empty, so a thread walks its triangle's slots
     int tiles_x;
     int band_ty0, band_ty1;
     int width, height;
@@ -35,14 +37,15 @@ struct BinArgs {
 // finds nothing, so dropping the pair changes no pixel and no counter.
 //
 // Proof sketch.  Let R be the pixel rectangle bbox /\ tile and, for edge k with float coefficients (a, b) and
-// reference vertex (rx, ry), E(x,y) = a*(x-rx) + b*(y-ry) in real arithmetic.  Every value the float chain
-// takes is fl-arithmetic on points of R: the start value costs <= 5 roundings of quantities bounded by
-// M = |a|*max|x-rx| + |b|*max|y-ry| over R, and each of the <= 30 chain adds rounds a value of magnitude
-// <= M(1+tiny); so |W - E| <= 35 * 2^-24 * M(1+tiny) at every pixel of R.  With delta = 64 * 2^-24 * M:
-// max_R E < -delta  =>  W < 0 on all of R (kills "all >= 0");  min_R E > delta  =>  W > 0 on all of R (kills
-// "all <= 0").  E is linear, so its extrema over R are at corners; they are evaluated in fp64, where the
-// products (24-bit x <= 29-bit) are exact and the one addition's error is ~2^-29 of delta.  NaN / Inf inputs
-// make every comparison false, i.e. "keep".
+// reference vertex (rx, ry), E(x,y) = a*(x-rx) + b*(y-ry) in real arithmetic; u = 2^-24.  Every value the
+// reference's float chain takes is fl-arithmetic on points of R: the start value costs <= 5 roundings of
+// quantities bounded by M = |a|*max|x-rx| + |b|*max|y-ry| over R, and each of the <= 30 chain adds rounds a value
+// of magnitude <= M(1+tiny); so |W - E| <= 35uM(1+tiny) at every pixel of R.  E is linear, so its extrema over R
+// are at corners; evaluating them in float32 as below costs <= 3 roundings per term, |Efl - E| <= 6uM, and the
+// float M' satisfies M' >= M(1-4u).  With delta = 64uM':
+//   Efl_max < -delta  =>  W <= E_max + 35uM <= Efl_max + 41uM < -64uM(1-4u) + 41uM < 0 on all of R  (kills "all >= 0")
+//   Efl_min >  delta  =>  W > 0 on all of R                                                          (kills "all <= 0")
+// NaN / Inf inputs make the finiteness test or the comparisons false, i.e. "keep".
 __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy[3], int minX, int maxX, int minY, int maxY,
                                                int tx, int ty, int width, int height, bool is_line) {
     if (is_line) return true;         // DrawLine edges: keep every tile of the line's bbox (the test below is for triangles)
@@ -55,19 +58,19 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
     const float eb[3] = { sx[2] - sx[1], sx[0] - sx[2], sx[1] - sx[0] };   // b12, b20, b01
     const float rx[3] = { sx[1], sx[2], sx[0] };
     const float ry[3] = { sy[1], sy[2], sy[0] };
+    const float fxs = (float)startX, fxe = (float)endX, fys = (float)startY, fye = (float)endY;
     bool any_neg = false, any_pos = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double a = (double)ea[k], b = (double)eb[k];
-        const double dxs = (double)startX - (double)rx[k], dxe = (double)endX - (double)rx[k];
-        const double dys = (double)startY - (double)ry[k], dye = (double)endY - (double)ry[k];
-        const double ax_s = a * dxs, ax_e = a * dxe, by_s = b * dys, by_e = b * dye;
-        const double emax = fmax(ax_s, ax_e) + fmax(by_s, by_e);
-        const double emin = fmin(ax_s, ax_e) + fmin(by_s, by_e);
-        const double m = fabs(a) * fmax(fabs(dxs), fabs(dxe)) + fabs(b) * fmax(fabs(dys), fabs(dye));
-        const double delta = m * (64.0 / 16777216.0);
-        // fmax/fmin drop NaNs, so test finiteness explicitly: a non-finite term means "cannot prove anything"
-        const bool finite = (m == m) && (m < 1.0e300);
+        const float a = ea[k], b = eb[k];
+        const float dxs = fxs - rx[k], dxe = fxe - rx[k], dys = fys - ry[k], dye = fye - ry[k];
+        const float ax_s = a * dxs, ax_e = a * dxe, by_s = b * dys, by_e = b * dye;
+        const float emax = fmaxf(ax_s, ax_e) + fmaxf(by_s, by_e);
+        const float emin = fminf(ax_s, ax_e) + fminf(by_s, by_e);
+        const float m = fabsf(a) * fmaxf(fabsf(dxs), fabsf(dxe)) + fabsf(b) * fmaxf(fabsf(dys), fabsf(dye));
+        const float delta = m * (64.0f / 16777216.0f);
+        // fmaxf/fminf drop NaNs, so test finiteness explicitly: a non-finite term means "cannot prove anything"
+        const bool finite = m < 1.0e30f && ax_s == ax_s && ax_e == ax_e && by_s == by_s && by_e == by_e;
         any_neg = any_neg || (finite && emax < -delta);
         any_pos = any_pos || (finite && emin > delta);
     }
@@ -77,35 +80,41 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
 // Adds (tile, slot) pairs for the lanes with want == true.  Lanes of a wave usually hold neighbouring triangles
 // of one mesh, i.e. few distinct tiles: one atomic per DISTINCT tile per call (leader election by ballot),
 // ranks inside the group by mbcnt.  The order inside a tile's list is irrelevant here (k_sort_tiles fixes it).
+// Adds (tile, slot) pairs for the lanes with want == true.  Lanes of a wave usually hold neighbouring triangles
+// of one mesh, i.e. few distinct tiles: one atomic per DISTINCT tile per call (leader election by ballot),
+// ranks inside the group by mbcnt.  The order inside a tile's list is irrelevant here (k_sort_tiles fixes it).
+// Split in two so that a caller can issue the atomics of ALL its steps before consuming any returned base
+// (each consumption costs an atomic round trip).
+struct BinTicket { int leader; uint32_t rank; uint32_t base_reg; };
+
 template <bool FILL>
-__device__ __forceinline__ void bin_wave(const BinArgs& a, bool want, uint32_t tile, uint32_t slot) {
+__device__ __forceinline__ BinTicket bin_issue(const BinArgs& a, bool want, uint32_t tile) {
     const int lane = (int)(threadIdx.x & 63u);
     unsigned long long todo = __ballot(want);
-    int my_leader = lane;
-    uint32_t my_rank = 0, base_reg = 0;
+    BinTicket t; t.leader = lane; t.rank = 0; t.base_reg = 0;
     while (todo) {
         const int leader = __ffsll((long long)todo) - 1;
         const uint32_t t0 = (uint32_t)__shfl((int)tile, leader);
         const bool in_group = want && tile == t0;
         const unsigned long long same = __ballot(in_group);
         if (in_group) {
-            my_leader = leader;
-            my_rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+            t.leader = leader;
+            t.rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
         }
         if (lane == leader) {
-            // the returned base is only consumed after the loop, so the atomics of all groups are in flight together
-            if (FILL) base_reg = atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
+            if (FILL) t.base_reg = atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
             else atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
         }
         todo &= ~same;
     }
-    if (FILL) {
-        const uint32_t base = (uint32_t)__shfl((int)base_reg, my_leader);
-        if (want) {
-            const uint32_t at = a.tile_start[tile] + base + my_rank;
-            if (at < a.list_capacity) a.tile_list[at] = slot;
-            else a.counters->overflow = 1u;
-        }
+    return t;
+}
+__device__ __forceinline__ void bin_commit(const BinArgs& a, const BinTicket& t, bool want, uint32_t tile, uint32_t slot) {
+    const uint32_t base = (uint32_t)__shfl((int)t.base_reg, t.leader);
+    if (want) {
+        const uint32_t at = a.tile_start[tile] + base + t.rank;
+        if (at < a.list_capacity) a.tile_list[at] = slot;
+        else a.counters->overflow = 1u;
     }
 }
 
@@ -113,78 +122,96 @@ __device__ __forceinline__ void bin_wave(const BinArgs& a, bool want, uint32_t t
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     if (FILL && a.ctrl->poison) return;
-    const uint32_t slot = a.slot_lo + blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int tminx = 0, tminy = 0, nx = 0, ny = 0;
-    float sx[3] = { 0.f, 0.f, 0.f }, sy[3] = { 0.f, 0.f, 0.f };
-    int minX = 0, maxX = -1, minY = 0, maxY = -1;
-    bool is_line = false;
-    if (slot < a.slot_hi) {
-        unsigned long long tb = a.slot_tb[slot];
-        if (tb != SWR_TB_INVALID) {
-            tminx = (int)(tb & 0xffff);
-            int tmaxx = (int)((tb >> 16) & 0xffff);
-            tminy = (int)((tb >> 32) & 0xffff);
-            int tmaxy = (int)((tb >> 48) & 0xffff);
-            tminy = max(tminy, a.band_ty0);
-            tmaxy = min(tmaxy, a.band_ty1 - 1);
-            nx = tmaxx - tminx + 1;
-            ny = tmaxy - tminy + 1;
-            if (ny <= 0) { nx = 0; ny = 0; }
-            else {
-                const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
-                const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
-                sx[0] = r0.x; sx[1] = r0.y; sx[2] = r0.z; sy[0] = r0.w; sy[1] = r1.x; sy[2] = r1.y;
-                const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
-                minX = (int)(bbx & 0xffffu); maxX = (int)(bbx >> 16); minY = (int)(bby & 0xffffu); maxY = (int)(bby >> 16);
-                is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+    const uint32_t first = a.slot_lo + (blockIdx.x * 256u + threadIdx.x) * a.spt;
+    for (uint32_t si = 0; si < a.spt; ++si) {
+        const uint32_t slot = first + si;
+        int tminx = 0, tminy = 0, nx = 0, ny = 0;
+        float sx[3] = { 0.f, 0.f, 0.f }, sy[3] = { 0.f, 0.f, 0.f };
+        int minX = 0, maxX = -1, minY = 0, maxY = -1;
+        bool is_line = false;
+        if (slot < a.slot_hi) {
+            unsigned long long tb = a.slot_tb[slot];
+            if (tb != SWR_TB_INVALID) {
+                tminx = (int)(tb & 0xffff);
+                int tmaxx = (int)((tb >> 16) & 0xffff);
+                tminy = (int)((tb >> 32) & 0xffff);
+                int tmaxy = (int)((tb >> 48) & 0xffff);
+                tminy = max(tminy, a.band_ty0);
+                tmaxy = min(tmaxy, a.band_ty1 - 1);
+                nx = tmaxx - tminx + 1;
+                ny = tmaxy - tminy + 1;
+                if (ny <= 0) { nx = 0; ny = 0; }
+                else {
+                    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
+                    const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
+                    sx[0] = r0.x; sx[1] = r0.y; sx[2] = r0.z; sy[0] = r0.w; sy[1] = r1.x; sy[2] = r1.y;
+                    const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
+                    minX = (int)(bbx & 0xffffu); maxX = (int)(bbx >> 16); minY = (int)(bby & 0xffffu); maxY = (int)(bby >> 16);
+                    is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+                }
             }
         }
-    }
-    const int nt = nx * ny;
-    const bool big = nt > 8;
-    {
-        int nt_small = big ? 0 : nt, nt_max = nt_small;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) nt_max = max(nt_max, __shfl_xor(nt_max, off));
-        for (int i = 0; i < nt_max; ++i) {
-            bool want = i < nt_small;
-            int ty = 0, tx = 0;
-            if (want) {
-                ty = tminy + i / nx; tx = tminx + i % nx;
-                want = pair_may_cover(sx, sy, minX, maxX, minY, maxY, tx, ty, a.width, a.height, is_line);
+        const int nt = nx * ny;
+        const bool big = nt > 8;
+        {
+            // small triangles (<= 8 tiles of bbox): step i handles every lane's i-th tile; all atomics first, then the stores
+            const int nt_small = big ? 0 : nt;
+            int nt_max = nt_small;
+    #pragma unroll
+            for (int off = 32; off > 0; off >>= 1) nt_max = max(nt_max, __shfl_xor(nt_max, off));
+            bool want[8];
+            uint32_t tile[8];
+            BinTicket tk[8];
+            int wtx = tminx, wty = tminy;                 // row-major walk of the tile bbox without integer division
+    #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                want[i] = false; tile[i] = 0;
+                if (i < nt_max) {
+                    if (i < nt_small) {
+                        want[i] = pair_may_cover(sx, sy, minX, maxX, minY, maxY, wtx, wty, a.width, a.height, is_line);
+                        tile[i] = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
+                        ++wtx;
+                        if (wtx >= tminx + nx) { wtx = tminx; ++wty; }
+                    }
+                    tk[i] = bin_issue<FILL>(a, want[i], tile[i]);
+                }
             }
-            bin_wave<FILL>(a, want, (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx), slot);
+            if (FILL) {
+    #pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (i < nt_max) bin_commit(a, tk[i], want[i], tile[i], slot);
+            }
         }
-    }
-    unsigned long long m = __ballot(big);
-    while (m) {
-        const int src = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int s_tminx = __shfl(tminx, src), s_tminy = __shfl(tminy, src);
-        const int s_nx = __shfl(nx, src), s_nt = __shfl(nt, src);
-        const uint32_t s_slot = (uint32_t)__shfl((int)slot, src);
-        float bsx[3], bsy[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
-        const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
-        const bool b_line = __shfl((int)is_line, src) != 0;
-        for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
-            const int i = i0 + lane;
-            bool want = i < s_nt;
-            int ty = 0, tx = 0;
-            if (want) {
-                ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
-                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
-            }
-            if (want) {
-                const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
-                if (FILL) {
-                    const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
-                    if (at < a.list_capacity) a.tile_list[at] = s_slot;
-                    else a.counters->overflow = 1u;
-                } else {
-                    atomicAdd(&a.tile_count[tile], 1u);
+        unsigned long long m = __ballot(big);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int s_tminx = __shfl(tminx, src), s_tminy = __shfl(tminy, src);
+            const int s_nx = __shfl(nx, src), s_nt = __shfl(nt, src);
+            const uint32_t s_slot = (uint32_t)__shfl((int)slot, src);
+            float bsx[3], bsy[3];
+    #pragma unroll
+            for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
+            const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
+            const bool b_line = __shfl((int)is_line, src) != 0;
+            for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
+                const int i = i0 + lane;
+                bool want = i < s_nt;
+                int ty = 0, tx = 0;
+                if (want) {
+                    ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
+                    want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
+                }
+                if (want) {
+                    const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                    if (FILL) {
+                        const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
+                        if (at < a.list_capacity) a.tile_list[at] = s_slot;
+                        else a.counters->overflow = 1u;
+                    } else {
+                        atomicAdd(&a.tile_count[tile], 1u);
+                    }
                 }
             }
         }
