@@ -416,7 +416,15 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
             for (auto& d : b.draws) phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
             if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);
             else if (phong) hipLaunchKernelGGL((k_raster_c<false, true>), g, t, 0, c->stream, ra, mk, pc);
-            else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
+            else {
+                // the reference's own frame: every mesh drawn with Renderer's shader pair and the RenderMesh defaults
+                bool dust2_default = true;
+                for (auto& d : b.draws) dust2_default = dust2_default && d.p.program == SWR_PROG_DUST2_LAMBERT_FOG &&
+                                                        d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
+                if (dust2_default)
+                    hipLaunchKernelGGL((k_raster_c<false, false, SWR_PROG_DUST2_LAMBERT_FOG, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
+                else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
+            }
         }
         SWR_HIP(c, hipGetLastError());
         cc = cd = false;

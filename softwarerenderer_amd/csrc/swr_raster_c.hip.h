@@ -163,7 +163,9 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 #ifndef SWR_RASTER_WPB
 #define SWR_RASTER_WPB 1
 #endif
-template <bool LINES, bool PHONG>
+// PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
+// the switches fold away); -1 = read them from the draw at run time.
+template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1>
 __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
     __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
             const bool act = lane < cut;
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
-            const int f_program = cdp->program, f_blend = cdp->blend, f_dt = cdp->depth_test;
+            const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
             if (act) {
                 const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
                 const float d0 = f1.z, d1 = f1.w, d2 = f2.x, inv_area = f2.y;
