@@ -170,6 +170,19 @@ int  swr_render_mesh_arrays(swr_context* ctx, const swr_vertex* vertices, int n_
                             const float model[16], const float view[16], const float projection[16],
                             int program, const swr_uniforms* uniforms, const swr_texture* texture,
                             int cull_mode, int depth_test, int blend_mode);
+/* FrustumCuller.cs on the GPU (row N3) ------------------------------------------------------- */
+/* Mesh.SphereBounds = FrustumCuller.CalculateBoundingSphere(vertices) (FrustumCuller.cs:59-151, ModelLoader.cs:291),
+ * computed once per retained mesh in the serial schedule of the reference's loops; out = {cx, cy, cz, radius} */
+int  swr_mesh_bounds(swr_context* ctx, const swr_mesh* mesh, float center_radius[4]);
+/* FrustumCuller.IsSphereInFrustum(bounds, model, view, projection), FrustumCuller.cs:201-218 */
+int  swr_is_sphere_in_frustum(swr_context* ctx, const float center_radius[4], const float model[16], const float view[16],
+                              const float projection[16], int* inside);
+/* `if (!IsSphereInFrustum(mesh.SphereBounds, ...)) return; RenderMesh(...)` of Renderer.cs:446-459, with the test
+ * evaluated on the device at flush time (one thread per draw): a culled mesh costs no host round trip */
+int  swr_render_mesh_culled(swr_context* ctx, const swr_mesh* mesh,
+                            const float model[16], const float view[16], const float projection[16],
+                            int program, const swr_uniforms* uniforms, const swr_texture* texture,
+                            int cull_mode, int depth_test, int blend_mode);
 int  swr_flush(swr_context* ctx);    /* execute recorded draws (asynchronous on the stream) */
 int  swr_sync(swr_context* ctx);     /* flush + wait for the stream */
 

@@ -69,6 +69,8 @@ def load(fma: bool = False) -> C.CDLL:
     lib.oswr_depth_func.restype = I; lib.oswr_depth_func.argtypes = [I, F, F]
     lib.oswr_edge_function.restype = F; lib.oswr_edge_function.argtypes = [P, P, P]
     lib.oswr_numerics_fma.restype = I; lib.oswr_numerics_fma.argtypes = []
+    lib.oswr_bounding_sphere.restype = None; lib.oswr_bounding_sphere.argtypes = [P, I, P]
+    lib.oswr_is_sphere_in_frustum.restype = I; lib.oswr_is_sphere_in_frustum.argtypes = [P, P, P, P]
     _libs[name] = lib
     return lib
 

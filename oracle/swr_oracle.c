@@ -730,3 +730,73 @@ int oswr_render_mesh(oswr_context* c,
     free(th_); free(args);
     return 0;
 }
+
+/* ---------- FrustumCuller.cs ---------- */
+static inline float dist_sq3(const float a[3], const float b[3]) {       /* Vector3.DistanceSquared */
+    float d[3] = { a[0] - b[0], a[1] - b[1], a[2] - b[2] };
+    return vec3_dot(d, d);
+}
+void oswr_bounding_sphere(const oswr_vertex_input* v, int n, float out[4]) {          /* FrustumCuller.cs:59-151 */
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    if (n == 0) return;                                                               /* :65-66 */
+    if (n == 1) { memcpy(out, v[0].position, 12); return; }                           /* :67-68 */
+    float p0[3], p1[3], p2[3];
+    memcpy(p0, v[0].position, 12); memcpy(p1, p0, 12);
+    float max_sq = 0.0f;
+    for (int i = 1; i < n; ++i) {                                                     /* :75-93 */
+        float d = dist_sq3(v[i].position, p0);
+        if (d > max_sq) { max_sq = d; memcpy(p1, v[i].position, 12); }
+    }
+    memcpy(p2, p1, 12); max_sq = 0.0f;
+    for (int i = 0; i < n; ++i) {                                                     /* :98-116 */
+        float d = dist_sq3(v[i].position, p1);
+        if (d > max_sq) { max_sq = d; memcpy(p2, v[i].position, 12); }
+    }
+    float c[3] = { (p1[0] + p2[0]) * 0.5f, (p1[1] + p2[1]) * 0.5f, (p1[2] + p2[2]) * 0.5f };   /* :118 */
+    float r = sqrtf(max_sq) * 0.5f;                                                   /* :119 */
+    float nc[3] = { c[0], c[1], c[2] }, nr = r;
+    int found = 0; float fpos[3] = { 0, 0, 0 }, fdist = 0.0f;
+    for (int i = 0; i < n; ++i) {                                                     /* :124-131: local keeps the LAST one */
+        float dist = sqrtf(dist_sq3(v[i].position, c));
+        if (dist > r) { found = 1; fdist = dist; memcpy(fpos, v[i].position, 12); }
+    }
+    if (found && fdist > nr) {                                                        /* :133-147 */
+        float upd = (nr + fdist) * 0.5f;
+        float k = (upd - nr) / fdist;
+        for (int j = 0; j < 3; ++j) { float t = (fpos[j] - nc[j]) * k; nc[j] = nc[j] + t; }
+        nr = upd;
+    }
+    out[0] = nc[0]; out[1] = nc[1]; out[2] = nc[2]; out[3] = nr;
+}
+
+/* Plane ctor normalises again (FrustumCuller.cs:25-29) after NormalizePlane (:189-199) */
+static void make_plane(float x, float y, float z, float w, float pl[4]) {
+    float mag = sqrtf((x * x + y * y) + z * z);
+    float n[3] = { x / mag, y / mag, z / mag }, nn[3];
+    vec3_normalize(n, nn);
+    pl[0] = nn[0]; pl[1] = nn[1]; pl[2] = nn[2]; pl[3] = w / mag;
+}
+int oswr_is_sphere_in_frustum(const float sphere[4], const float model[16], const float view[16], const float proj[16]) {
+    float c4[4] = { sphere[0], sphere[1], sphere[2], 1.0f }, wc[4];
+    vec4_transform(c4, model, wc);                                                    /* Vector3.Transform(center, model) :203 */
+    const float* m = model;
+    float s0 = sqrtf((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]);                       /* :204-209 */
+    float s1 = sqrtf((m[4] * m[4] + m[5] * m[5]) + m[6] * m[6]);
+    float s2 = sqrtf((m[8] * m[8] + m[9] * m[9]) + m[10] * m[10]);
+    float max_scale = mathf_max(mathf_max(s0, s1), s2);
+    float wr = sphere[3] * max_scale;                                                 /* :211 */
+    float vp[16];                                                                     /* Matrix4x4.Multiply(view, proj) :212 */
+    for (int i = 0; i < 4; ++i) vec4_transform(view + 4 * i, proj, vp + 4 * i);
+    /* planes in the reference's test order: Left, Right, Top, Bottom, Near, Far (:213-218); M_rc = vp[(r-1)*4 + (c-1)] */
+    const int col[6] = { 0, 0, 1, 1, 2, 2 };
+    const float sgn[6] = { 1.0f, -1.0f, 1.0f, -1.0f, 1.0f, -1.0f };
+    for (int k = 0; k < 6; ++k) {
+        float co[4];
+        for (int r = 0; r < 4; ++r) co[r] = sgn[k] > 0 ? vp[r * 4 + 3] + vp[r * 4 + col[k]] : vp[r * 4 + 3] - vp[r * 4 + col[k]];
+        float pl[4];
+        make_plane(co[0], co[1], co[2], co[3], pl);
+        float dist = vec3_dot(pl, wc) + pl[3];                                        /* GetDistanceToPoint :31-34 */
+        if (!(dist > -wr)) return 0;                                                  /* :221-224 */
+    }
+    return 1;
+}

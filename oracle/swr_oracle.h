@@ -134,6 +134,13 @@ int   oswr_depth_func(int test, float new_depth, float old_depth);
 float oswr_edge_function(const float a[2], const float b[2], const float c[2]);
 int   oswr_numerics_fma(void);
 
+/* FrustumCuller.cs (row N3 of SURVEY.md section 8f) */
+/* CalculateBoundingSphere, FrustumCuller.cs:59-151, in the serial schedule of its Parallel.For loops (one partition:
+ * the third pass then applies ONE update with the LAST vertex found outside the first sphere). out = {cx,cy,cz,r} */
+void  oswr_bounding_sphere(const oswr_vertex_input* vertices, int n_vertices, float out[4]);
+/* IsSphereInFrustum, FrustumCuller.cs:201-218 */
+int   oswr_is_sphere_in_frustum(const float sphere[4], const float model[16], const float view[16], const float projection[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,8 +11,8 @@ Layout:
 
 Importing the package does not touch the GPU; creating a `Device` does.
 """
-from .rasterizer import (BlendMode, CullMode, DebugMode, DepthTest, Device, MainWindow, Mesh, Program,  # noqa: F401
+from .rasterizer import (BlendMode, CullMode, DebugMode, DepthTest, Device, FrustumCuller, MainWindow, Mesh, Program,  # noqa: F401
                          Rasterizer, ShaderProgram, Shaders, Texture, VERTEX_DTYPE, default_uniforms)
 
-__all__ = ["BlendMode", "CullMode", "DebugMode", "DepthTest", "Device", "MainWindow", "Mesh", "Program",
+__all__ = ["BlendMode", "CullMode", "DebugMode", "DepthTest", "Device", "FrustumCuller", "MainWindow", "Mesh", "Program",
            "Rasterizer", "ShaderProgram", "Shaders", "Texture", "VERTEX_DTYPE", "default_uniforms"]

@@ -65,7 +65,7 @@ EXPORTS = [
     "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_upload", "swr_color_device_ptr",
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
-    "swr_render_mesh_arrays", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
+    "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
     "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters",
 ]
 
@@ -113,6 +113,9 @@ def load() -> C.CDLL:
         "swr_initialize_tile_locks": (I, [P, I, I]),
         "swr_render_mesh": (I, [P, P, fp, fp, fp, I, C.POINTER(Uniforms), P, I, I, I]),
         "swr_render_mesh_arrays": (I, [P, P, I, P, I, fp, fp, fp, I, C.POINTER(Uniforms), P, I, I, I]),
+        "swr_mesh_bounds": (I, [P, P, fp]),
+        "swr_is_sphere_in_frustum": (I, [P, fp, fp, fp, fp, C.POINTER(I)]),
+        "swr_render_mesh_culled": (I, [P, P, fp, fp, fp, I, C.POINTER(Uniforms), P, I, I, I]),
         "swr_flush": (I, [P]),
         "swr_sync": (I, [P]),
         "swr_interpolate": (I, [P, P, P, I, I, P]),

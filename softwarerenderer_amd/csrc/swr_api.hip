@@ -22,10 +22,13 @@
 #include "swr_raster_q.hip.h"
 #include "swr_raster_b.hip.h"
 #include "swr_raster_c.hip.h"
+#include "swr_cull.hip.h"
 
 using namespace swr;
 
 struct swr_mesh {
+    float4* d_bounds = nullptr;               // Mesh.SphereBounds (ModelLoader.cs:291), computed on first use
+    bool bounds_ready = false;
     swr_vertex* d_verts = nullptr;
     uint16_t* d_idx = nullptr;
     int n_verts = 0, n_idx = 0;
@@ -56,6 +59,7 @@ struct FrameSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullp
 struct DrawCmd {
     DrawParams p;
     swr_mesh* mesh;
+    bool frustum_cull = false;                 // render only if IsSphereInFrustum(mesh bounds, model, view, proj)
 };
 
 // one flush = one batch; kept until the host has seen that it fitted (optimistic execution, see swr::Ctrl)
@@ -247,6 +251,7 @@ void free_garbage(swr_context* c) {       // stream must be idle
     for (swr_mesh* m : c->garbage) {
         if (m->d_verts) (void)hipFree(m->d_verts);
         if (m->d_idx) (void)hipFree(m->d_idx);
+        if (m->d_bounds) (void)hipFree(m->d_bounds);
         delete m;
     }
     c->garbage.clear();
@@ -460,7 +465,11 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
 
     const size_t off_vb = (nd * sizeof(DrawParams) + 255) & ~(size_t)255;
     const size_t off_tb = (off_vb + vblocks.size() * sizeof(BlockMap) + 255) & ~(size_t)255;
-    const size_t up_bytes = off_tb + tblocks.size() * sizeof(BlockMap);
+    bool any_cull = false;
+    for (auto& d : b.draws) any_cull = any_cull || d.frustum_cull;
+    const size_t off_bp = (off_tb + tblocks.size() * sizeof(BlockMap) + 255) & ~(size_t)255;     // per-draw bounds pointers
+    const size_t off_vis = (off_bp + (any_cull ? nd * sizeof(void*) : 0) + 255) & ~(size_t)255;   // per-draw visibility words
+    const size_t up_bytes = off_vis + (any_cull ? nd * 4 : 0);
     if ((rc = ensure(c, c->d_upload, up_bytes))) return rc;
     if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
     if ((rc = ensure(c, c->d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
@@ -477,17 +486,30 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     memcpy(stage, hp.data(), nd * sizeof(DrawParams));
     if (!vblocks.empty()) memcpy(stage + off_vb, vblocks.data(), vblocks.size() * sizeof(BlockMap));
     memcpy(stage + off_tb, tblocks.data(), tblocks.size() * sizeof(BlockMap));
+    if (any_cull) {
+        const float4** bp = reinterpret_cast<const float4**>(stage + off_bp);
+        for (size_t i = 0; i < nd; ++i) bp[i] = b.draws[i].frustum_cull ? b.draws[i].mesh->d_bounds : nullptr;
+    }
     SWR_HIP(c, hipMemcpyAsync(c->d_upload.p, stage, up_bytes, hipMemcpyHostToDevice, c->stream));
     const DrawParams* d_draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
     const BlockMap* d_vblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_vb);
     const BlockMap* d_tblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_tb);
 
+    const uint32_t* d_visible = nullptr;
+    if (any_cull) {
+        ScopedSpan sp(c, ST_VERTEX);
+        uint32_t* vis = reinterpret_cast<uint32_t*>((char*)c->d_upload.p + off_vis);
+        hipLaunchKernelGGL(k_frustum_cull, dim3((unsigned)((nd + 63) / 64)), dim3(64), 0, c->stream, d_draws,
+                           reinterpret_cast<const float4* const*>((char*)c->d_upload.p + off_bp), (uint32_t)nd, vis);
+        SWR_HIP(c, hipGetLastError());
+        d_visible = vis;
+    }
     FrameParams fp = frame_params(c);
     fp.near_clip = b.near_clip;
     if (!vblocks.empty()) {
         ScopedSpan sp(c, ST_VERTEX);
         hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
-                           d_draws, d_vblocks, c->d_vout.as<VOut>());
+                           d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -496,7 +518,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            d_draws, d_tblocks, (const VOut*)c->d_vout.as<VOut>(),
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
-                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0);
+                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible);
         SWR_HIP(c, hipGetLastError());
     }
     rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), immediate, mode);
@@ -571,8 +593,17 @@ int flush_locked(swr_context* c) {
     return rc;
 }
 
+int ensure_bounds(swr_context* c, swr_mesh* m) {
+    if (m->bounds_ready) return SWR_OK;
+    if (!m->d_bounds) SWR_HIP(c, hipMalloc((void**)&m->d_bounds, sizeof(float4)));
+    hipLaunchKernelGGL(k_bounding_sphere, dim3(1), dim3(1024), 0, c->stream, (const swr_vertex*)m->d_verts, (uint32_t)m->n_verts, m->d_bounds);
+    SWR_HIP(c, hipGetLastError());
+    m->bounds_ready = true;
+    return SWR_OK;
+}
+
 int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
-                int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
+                int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend, bool frustum_cull = false) {
     if (!mesh || !model || !view || !proj) return fail(c, SWR_ERR_INVALID_ARG, "null argument to render_mesh");
     if (program < SWR_PROG_FLAT_COLOR || program > SWR_PROG_PHONG_4POINT)
         return fail(c, SWR_ERR_INVALID_ARG, "unknown program id");
@@ -598,6 +629,8 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
     d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
     d.mesh = mesh;
+    d.frustum_cull = frustum_cull;
+    if (frustum_cull) { int rc = ensure_bounds(c, mesh); if (rc) return rc; }
     c->draws.push_back(d);
     c->pend_verts += mesh->n_verts; c->pend_tris += n_tris;
     return SWR_OK;
@@ -905,6 +938,7 @@ int swr_mesh_destroy(swr_context* c, swr_mesh* m) {
     if ((rc = sync_locked(c))) return rc;
     if (m->d_verts) (void)hipFree(m->d_verts);
     if (m->d_idx) (void)hipFree(m->d_idx);
+    if (m->d_bounds) (void)hipFree(m->d_bounds);
     delete m;
     return SWR_OK;
 }
@@ -930,6 +964,43 @@ int swr_render_mesh(swr_context* c, const swr_mesh* mesh, const float model[16],
                     int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
     SWR_ENTER(c);
     return record_draw(c, const_cast<swr_mesh*>(mesh), model, view, proj, program, u, tex, cull, depth_test, blend);
+}
+
+int swr_render_mesh_culled(swr_context* c, const swr_mesh* mesh, const float model[16], const float view[16], const float proj[16],
+                           int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend) {
+    SWR_ENTER(c);
+    return record_draw(c, const_cast<swr_mesh*>(mesh), model, view, proj, program, u, tex, cull, depth_test, blend, true);
+}
+
+int swr_mesh_bounds(swr_context* c, const swr_mesh* mesh, float center_radius[4]) {
+    SWR_ENTER(c);
+    if (!mesh || !center_radius) return fail(c, SWR_ERR_INVALID_ARG, "bad mesh_bounds arguments");
+    int rc = ensure_bounds(c, const_cast<swr_mesh*>(mesh));
+    if (rc) return rc;
+    SWR_HIP(c, hipMemcpyAsync(center_radius, mesh->d_bounds, 16, hipMemcpyDeviceToHost, c->stream));
+    SWR_HIP(c, hipStreamSynchronize(c->stream));
+    return SWR_OK;
+}
+
+int swr_is_sphere_in_frustum(swr_context* c, const float center_radius[4], const float model[16], const float view[16],
+                             const float proj[16], int* inside) {
+    SWR_ENTER(c);
+    if (!center_radius || !model || !view || !proj || !inside) return fail(c, SWR_ERR_INVALID_ARG, "bad is_sphere_in_frustum arguments");
+    int rc = ensure(c, c->d_scratch, 256);
+    if (rc) return rc;
+    float h[48];
+    memcpy(h, model, 64); memcpy(h + 16, view, 64); memcpy(h + 32, proj, 64);
+    char* base = reinterpret_cast<char*>(c->d_scratch.p);
+    SWR_HIP(c, hipMemcpyAsync(base, h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_frustum_test, dim3(1), dim3(64), 0, c->stream,
+                       make_float4(center_radius[0], center_radius[1], center_radius[2], center_radius[3]),
+                       (const float*)base, (uint32_t*)(base + 192));
+    SWR_HIP(c, hipGetLastError());
+    uint32_t r = 0;
+    SWR_HIP(c, hipMemcpyAsync(&r, base + 192, 4, hipMemcpyDeviceToHost, c->stream));
+    SWR_HIP(c, hipStreamSynchronize(c->stream));
+    *inside = (int)r;
+    return SWR_OK;
 }
 
 int swr_render_mesh_arrays(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, int ni,

@@ -21,8 +21,9 @@ struct BlockMap { uint32_t draw; uint32_t first; };
 
 __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ draws,
                                                 const BlockMap* __restrict__ blocks,
-                                                VOut* __restrict__ vout) {
+                                                VOut* __restrict__ vout, const uint32_t* __restrict__ visible) {
     const BlockMap bm = blocks[blockIdx.x];
+    if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
     if (local >= dp->n_verts) return;
@@ -176,13 +177,21 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                unsigned long long* __restrict__ slot_tb,
                                                FrameParams fp,
                                                Counters* __restrict__ counters /* 64 replicas */,
-                                               const Ctrl* __restrict__ ctrl, int count_stats, int wireframe) {
+                                               const Ctrl* __restrict__ ctrl, int count_stats, int wireframe,
+                                               const uint32_t* __restrict__ visible) {
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
-    const bool active = local < dp->n_tris;
+    const bool in_range = local < dp->n_tris;
+    const bool drawn = !visible || visible[bm.draw] != 0u;     // frustum-culled draws: slots invalid, nothing counted
+    const bool active = in_range && drawn;
     unsigned n_setup = 0, n_clipped = 0;
 
+    if (in_range && !drawn) {
+        const uint32_t per_fan = wireframe ? 3u : 1u;
+        const uint32_t slot = 2u * per_fan * (dp->tri_base + local);
+        for (uint32_t k = 0; k < 2u * per_fan; ++k) slot_tb[slot + k] = SWR_TB_INVALID;
+    }
     if (active) {
         const uint32_t gt = dp->tri_base + local;
         const uint32_t per_fan = wireframe ? 3u : 1u;

@@ -321,10 +321,33 @@ class Mesh:
         self._h = C.c_void_p()
         device._ck(device._lib.swr_mesh_create(device._ctx, v.ctypes.data, self.n_vertices, i.ctypes.data, self.n_indices, C.byref(self._h)))
 
+    @property
+    def SphereBounds(self) -> np.ndarray:
+        """Mesh.SphereBounds = FrustumCuller.CalculateBoundingSphere(vertices) (ModelLoader.cs:291): {cx, cy, cz, r}, on the GPU."""
+        out = np.zeros(4, dtype=np.float32)
+        self._dev._ck(self._dev._lib.swr_mesh_bounds(self._dev._ctx, self._h, _fptr(out)))
+        return out
+
     def Dispose(self):
         if self._h:
             self._dev._ck(self._dev._lib.swr_mesh_destroy(self._dev._ctx, self._h))
             self._h = C.c_void_p()
+
+
+class FrustumCuller:
+    """public static class FrustumCuller (FrustumCuller.cs:57): the two members the frame loop uses."""
+
+    @staticmethod
+    def CalculateBoundingSphere(mesh: "Mesh") -> np.ndarray:          # FrustumCuller.cs:59-151
+        return mesh.SphereBounds
+
+    @staticmethod
+    def IsSphereInFrustum(window: "MainWindow", bounds, modelMatrix, viewMatrix, projectionMatrix) -> bool:   # :201-218
+        b, m, v, p = _f32(bounds, 4), _f32(modelMatrix, 16), _f32(viewMatrix, 16), _f32(projectionMatrix, 16)
+        out = C.c_int(0)
+        dev = window._dev
+        dev._ck(dev._lib.swr_is_sphere_in_frustum(dev._ctx, _fptr(b), _fptr(m), _fptr(v), _fptr(p), C.byref(out)))
+        return bool(out.value)
 
 
 def as_vertex_array(vertices) -> np.ndarray:
@@ -363,8 +386,9 @@ class Rasterizer:
     def RenderMesh(cls, window: MainWindow, vertices, indices, model, view, projection,
                    vertexShader: VertexShader, fragmentShader: FragmentShader,
                    cullMode: CullMode = CullMode.Back, depthTest: DepthTest = DepthTest.LessEqual,
-                   blendMode: BlendMode = BlendMode.Alpha):
-        """Rasterizer.RenderMesh, Rasterizer.cs:163-174.  `vertices` may be a retained `Mesh`
+                   blendMode: BlendMode = BlendMode.Alpha, frustumCull: bool = False):
+        """Rasterizer.RenderMesh, Rasterizer.cs:163-174.  frustumCull=True (retained meshes only) prepends the
+        reference's `if (!FrustumCuller.IsSphereInFrustum(mesh.SphereBounds, ...)) return;` (Renderer.cs:446), evaluated on the GPU.  `vertices` may be a retained `Mesh`
         (then `indices` is ignored) or the VertexInput[] / ushort[] arrays of the C# signature."""
         prog = fragmentShader.program
         if vertexShader.program is not prog:
@@ -374,7 +398,8 @@ class Rasterizer:
         m, v, p = _f32(model, 16), _f32(view, 16), _f32(projection, 16)
         tex = prog.texture._h if prog.texture is not None else None
         if isinstance(vertices, Mesh):
-            rc = dev._lib.swr_render_mesh(dev._ctx, vertices._h, _fptr(m), _fptr(v), _fptr(p), int(prog.program),
+            fn = dev._lib.swr_render_mesh_culled if frustumCull else dev._lib.swr_render_mesh
+            rc = fn(dev._ctx, vertices._h, _fptr(m), _fptr(v), _fptr(p), int(prog.program),
                                           C.byref(prog.uniforms), tex, int(cullMode), int(depthTest), int(blendMode))
         else:
             va = as_vertex_array(vertices)

@@ -213,3 +213,43 @@ def test_out_of_range_index_is_an_error(oracle_lib):
 def test_fma_variant_is_a_different_build(oracle_lib):
     assert oracle_lib.oswr_numerics_fma() == 0
     assert ob.load(fma=True).oswr_numerics_fma() == 1
+
+
+def test_bounding_sphere_serial_schedule_and_last_outside_vertex_quirk(oracle_lib):
+    """FrustumCuller.CalculateBoundingSphere (FrustumCuller.cs:59-151), hand-computed.
+    p0=(0,0,0) -> p1 = farthest from p0 = (4,0,0) -> p2 = farthest from p1 = (0,0,0): centre (2,0,0), r = 2.
+    The third loop's per-partition `local` keeps only the LAST vertex outside that sphere; with one partition the single
+    update uses (2,3,0) (distance 3): r' = 2.5, centre += (0,3,0) * (0.5/3) = (2,0.5,0) -- although (2,5,0) came first
+    and stays outside the result."""
+    def sphere(points):
+        v = scenes.make_vertices(points)
+        out = np.zeros(4, np.float32)
+        oracle_lib.oswr_bounding_sphere(v.ctypes.data, v.shape[0], out.ctypes.data)
+        return tuple(float(x) for x in out)
+    assert sphere([(0, 0, 0), (4, 0, 0)]) == (2.0, 0.0, 0.0, 2.0)
+    assert sphere([(0, 0, 0), (4, 0, 0), (2, 3, 0)]) == (2.0, 0.5, 0.0, 2.5)
+    # (2,3.4,0) is outside the first sphere too and comes first, but only the LAST outside vertex (2,3,0) is applied:
+    # same result as above, and (2,3.4,0) stays outside it (distance 2.9 from the new centre > 2.5)
+    assert sphere([(0, 0, 0), (4, 0, 0), (2, 3.4, 0), (2, 3, 0)]) == (2.0, 0.5, 0.0, 2.5)
+    assert sphere([(1, 2, 3)]) == (1.0, 2.0, 3.0, 0.0)                               # single vertex (:67-68)
+    assert sphere([(1, 2, 3), (1, 2, 3), (1, 2, 3)]) == (1.0, 2.0, 3.0, 0.0)         # nothing farther than 0: p1 = p2 = p0
+
+
+def test_sphere_in_frustum(oracle_lib):
+    """IsSphereInFrustum (FrustumCuller.cs:201-224): camera at the origin looking down -Z, fov 90, aspect 1."""
+    proj = hm.create_perspective_fov(np.pi / 2, 1.0, 0.1, 1000.0)
+    I = hm.identity()
+
+    def inside(c, r, model=I):
+        s = np.float32([c[0], c[1], c[2], r])
+        m, v, p = (np.ascontiguousarray(a, dtype=np.float32) for a in (model, I, proj))
+        return bool(oracle_lib.oswr_is_sphere_in_frustum(s.ctypes.data, m.ctypes.data, v.ctypes.data, p.ctypes.data))
+    assert inside((0, 0, -5), 1)
+    assert not inside((0, 0, 5), 1)                 # behind the camera: fails the near plane
+    assert inside((0, 0, 0.5), 1)                   # straddles the near plane
+    assert not inside((100, 0, -5), 1)              # right of the right plane (x = -z at fov 90)
+    assert inside((5.5, 0, -5), 1)                  # distance to the right plane = (5 - 5.5)/sqrt(2) = -0.35 > -1
+    assert not inside((7, 0, -5), 1)                # (5 - 7)/sqrt(2) = -1.41 < -1
+    # centre and radius both go through the model matrix: scale 0.5 -> centre (3.5,0,-2.5), r 0.5; (2.5-3.5)/sqrt(2) = -0.707 < -0.5
+    assert not inside((7, 0, -5), 1, model=hm.create_scale(0.5))
+    assert inside((5.5, 0, -5), 1, model=hm.create_scale(0.5))     # (2.5-2.75)/sqrt(2) = -0.18 > -0.5
