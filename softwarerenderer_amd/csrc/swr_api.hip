@@ -19,8 +19,6 @@
 #include "swr_geometry.hip.h"
 #include "swr_binning.hip.h"
 #include "swr_raster.hip.h"
-#include "swr_raster_q.hip.h"
-#include "swr_raster_b.hip.h"
 #include "swr_raster_c.hip.h"
 #include "swr_cull.hip.h"
 
@@ -115,8 +113,7 @@ struct swr_context {
     unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
 
     int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
-    bool force_immediate = false;             // SWR_RASTER=imm: always use k_raster (A/B and tests)
-    int raster_variant = 0;                   // SWR_RASTER=q: k_raster_q, b: k_raster_b; default k_cover + k_raster_c
+    bool force_immediate = false;             // SWR_RASTER=imm: always use the immediate-shading kernel k_raster (A/B and tests)
     std::vector<EventSpan> spans;
     std::vector<hipEvent_t> event_pool;
     swr_profile prof = {};
@@ -358,8 +355,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
         cover_items = (uint32_t)total;
     }
-    const int variant = b.wireframe ? 0 : c->raster_variant;      // only k_cover + k_raster_c know DrawLine records
-    const bool use_cover = !immediate && variant == 0;
+    const bool use_cover = !immediate;
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
@@ -411,8 +407,6 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         const unsigned quads = (unsigned)(ra.blocks_x * ra.blocks_y);
         // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
         if (immediate) hipLaunchKernelGGL(k_raster, dim3(quads), dim3(256), 0, c->stream, ra);
-        else if (variant == 1) hipLaunchKernelGGL(k_raster_q, dim3(quads), dim3(256), 0, c->stream, ra);
-        else if (variant == 2) hipLaunchKernelGGL(k_raster_b, dim3(quads), dim3(256), 0, c->stream, ra);
         else {
             const dim3 g(quads * (4u / SWR_RASTER_WPB)), t(64 * SWR_RASTER_WPB);
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
@@ -695,7 +689,7 @@ int swr_create(int device_id, swr_context** out) {
         g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
     }
     c->stream = c->own_stream;
-    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); c->raster_variant = (rv && !strcmp(rv, "q")) ? 1 : ((rv && !strcmp(rv, "b")) ? 2 : 0); }
+    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); }
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_ctrl, 64);

@@ -21,6 +21,15 @@
 
 namespace swr {
 
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
 struct CoverArgs {
     const TriRec* __restrict__ recs;
     const uint32_t* __restrict__ tile_list;   // sorted: slot id per pair

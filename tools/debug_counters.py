@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds a -DSWR_DEBUG_COUNTERS copy of the library into /tmp, renders one cfg frame and prints k_raster_b's work counters."""
+"""Builds a -DSWR_DEBUG_COUNTERS copy of the library into /tmp, renders one cfg frame and prints the raster kernel's work counters (historical: the counters lived in k_raster_b, removed since)."""
 import ctypes as C, os, subprocess, sys, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "softwarerenderer_amd", "csrc")
