@@ -225,6 +225,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
         L.owner[p] = 0xffffffffu;
     }
     unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+#ifdef SWR_DEBUG_COUNTERS
+    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0;
+#endif
 
     for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
         // ---- batch: the next (up to) 64 pairs of this tile; masks and counts staged in LDS ----
@@ -245,6 +248,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
         }
         if (lane == 0) L.pre[SWR_BATCH] = (uint32_t)total;
         n_tested += (unsigned)cnt;
+#ifdef SWR_DEBUG_COUNTERS
+        ++dbg_batches;
+#endif
 
         // ---- fragment stream of the batch, 64 at a time ----
         for (int pos = 0; pos < total;) {
@@ -306,6 +312,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
             if (valid) L.owner[pix] = 0xffffffffu;
             const bool act = lane < cut;
+#ifdef SWR_DEBUG_COUNTERS
+            ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
+#endif
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
@@ -377,6 +386,12 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
         uint32_t* ts = a.tile_stats + 3u * tile;
         ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
     }
+#ifdef SWR_DEBUG_COUNTERS
+    if (lane == 0 && a.dbg) {
+        atomicAdd(&a.dbg[0], (unsigned long long)dbg_batches); atomicAdd(&a.dbg[1], (unsigned long long)dbg_chunks);
+        atomicAdd(&a.dbg[4], (unsigned long long)dbg_chunk_lanes); atomicAdd(&a.dbg[3], (unsigned long long)dbg_chain);
+    }
+#endif
 }
 
 }  // namespace swr
