@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds a -DSWR_DEBUG_COUNTERS copy of the library into /tmp, renders one cfg frame and prints the raster kernel's work counters (historical: the counters lived in k_raster_b, removed since)."""
+"""Builds a -DSWR_DEBUG_COUNTERS copy of the library into /tmp, renders one cfg frame and prints k_raster_c's work counters (batches, chunks, chunk fill)."""
 import ctypes as C, os, subprocess, sys, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "softwarerenderer_amd", "csrc")
@@ -19,10 +19,10 @@ try:
     r.render()
     dev._lib.swr_debug_counters(dev._ctx, out)
     st = dev.stats()
-    names = ["batches", "chunks", "p1_max_iters", "chain_max_iters", "chunk_lanes", "tris"]
+    names = ["batches", "chunks", "unused2", "unused3", "chunk_lanes", "unused5"]
     d = dict(zip(names, [int(v) for v in out]))
     print(cfg, d)
-    print("pairs", d["tris"], "tris/batch", d["tris"] / max(d["batches"], 1), "p1 iters/batch", d["p1_max_iters"] / max(d["batches"], 1),
-          "frags/chunk", d["chunk_lanes"] / max(d["chunks"], 1), "chain iters/chunk", d["chain_max_iters"] / max(d["chunks"], 1))
+    print("pairs", st["tile_pairs"] // max(st["flushes"], 1), "batches", d["batches"], "chunks", d["chunks"],
+          "fragments per chunk", d["chunk_lanes"] / max(d["chunks"], 1))
 finally:
     shutil.move(bak, lib)
