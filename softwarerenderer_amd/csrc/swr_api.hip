@@ -113,7 +113,6 @@ struct swr_context {
     unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
 
     int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
-    bool force_immediate = false;             // SWR_RASTER=imm: always use the immediate-shading kernel k_raster (A/B and tests)
     std::vector<EventSpan> spans;
     std::vector<hipEvent_t> event_pool;
     swr_profile prof = {};
@@ -295,7 +294,7 @@ int run_clear(swr_context* c, bool& cc, bool& cd, const float rgba_[4]) {
 
 // bins slots [lo, hi) and rasterises them.  MODE_SYNC reads the pair total back (sizes buffers exactly, splits a
 // range that would need more than kMaxPairs entries); MODE_ASYNC launches everything against the current capacity.
-int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, bool immediate, int mode) {
+int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
@@ -342,8 +341,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
             // because the framebuffer carries the state from one round to the next.
             uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
             if (mid == lo) mid = lo + 2;
-            if ((rc = bin_and_raster(c, b, cc, cd, lo, mid, immediate, mode))) return rc;
-            return bin_and_raster(c, b, cc, cd, mid, hi, immediate, mode);
+            if ((rc = bin_and_raster(c, b, cc, cd, lo, mid, mode))) return rc;
+            return bin_and_raster(c, b, cc, cd, mid, hi, mode);
         }
         Counters* tp = c->d_counters.as<Counters>() + 64;          // tile_pairs of a round that really runs
         if (total == 0) return run_clear(c, cc, cd, b.clear_rgba);
@@ -355,7 +354,6 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
         cover_items = (uint32_t)total;
     }
-    const bool use_cover = !immediate;
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
@@ -368,7 +366,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
                            c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl);
         SWR_HIP(c, hipGetLastError());
     }
-    if (use_cover && cover_items) {
+    if (cover_items) {
         ScopedSpan sp(c, ST_COVER);
         CoverArgs ca;
         ca.recs = c->d_recs.as<TriRec>();
@@ -405,25 +403,24 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
         ra.ctrl = ctrl;
         const unsigned quads = (unsigned)(ra.blocks_x * ra.blocks_y);
-        // BlendMode.None needs the immediate-shading kernel (row early-out, Rasterizer.cs:520-523)
-        if (immediate) hipLaunchKernelGGL(k_raster, dim3(quads), dim3(256), 0, c->stream, ra);
-        else {
+        {
             const dim3 g(quads * (4u / SWR_RASTER_WPB)), t(64 * SWR_RASTER_WPB);
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
             const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
-            bool phong = false;
-            for (auto& d : b.draws) phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
-            if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);
-            else if (phong) hipLaunchKernelGGL((k_raster_c<false, true>), g, t, 0, c->stream, ra, mk, pc);
-            else {
+            bool phong = false, none = false, dust2_default = true;
+            for (auto& d : b.draws) {
+                phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
+                none = none || d.p.blend == SWR_BLEND_NONE;
                 // the reference's own frame: every mesh drawn with Renderer's shader pair and the RenderMesh defaults
-                bool dust2_default = true;
-                for (auto& d : b.draws) dust2_default = dust2_default && d.p.program == SWR_PROG_DUST2_LAMBERT_FOG &&
-                                                        d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
-                if (dust2_default)
-                    hipLaunchKernelGGL((k_raster_c<false, false, SWR_PROG_DUST2_LAMBERT_FOG, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
-                else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
+                dust2_default = dust2_default && d.p.program == SWR_PROG_DUST2_LAMBERT_FOG &&
+                                d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
             }
+            if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);   // DrawLine has no early-out
+            else if (none) hipLaunchKernelGGL((k_raster_c<false, true, -1, -1, -1, true>), g, t, 0, c->stream, ra, mk, pc);
+            else if (phong) hipLaunchKernelGGL((k_raster_c<false, true>), g, t, 0, c->stream, ra, mk, pc);
+            else if (dust2_default)
+                hipLaunchKernelGGL((k_raster_c<false, false, SWR_PROG_DUST2_LAMBERT_FOG, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
+            else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
         }
         SWR_HIP(c, hipGetLastError());
         cc = cd = false;
@@ -440,18 +437,15 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     std::vector<DrawParams> hp(nd);
     std::vector<BlockMap> vblocks, tblocks;
     uint64_t V = 0, T = 0;
-    bool immediate = c->force_immediate;
     for (size_t i = 0; i < nd; ++i) {
         DrawParams p = b.draws[i].p;
         p.vert_base = (uint32_t)V; p.tri_base = (uint32_t)T;
         for (uint32_t f = 0; f < p.n_verts; f += 256) vblocks.push_back({ (uint32_t)i, f });
         for (uint32_t f = 0; f < p.n_tris; f += 256) tblocks.push_back({ (uint32_t)i, f });
         V += p.n_verts; T += p.n_tris;
-        immediate = immediate || p.blend == SWR_BLEND_NONE;
         hp[i] = p;
     }
     const uint64_t spt = b.wireframe ? 6 : 2;        // primitive slots per submitted triangle
-    if (b.wireframe) immediate = false;              // DrawLine has no row early-out: always the cover + stream kernels
     if (V + 4 * T >= 0xffffffffull || spt * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, cc, cd, b.clear_rgba);
@@ -515,7 +509,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible);
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), immediate, mode);
+    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode);
     slot_submit(c);
     if (rc) return rc;
     if (cc || cd) return run_clear(c, cc, cd, b.clear_rgba);   // nothing was binned
@@ -689,7 +683,6 @@ int swr_create(int device_id, swr_context** out) {
         g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
     }
     c->stream = c->own_stream;
-    { const char* rv = getenv("SWR_RASTER"); c->force_immediate = rv && !strcmp(rv, "imm"); }
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_ctrl, 64);

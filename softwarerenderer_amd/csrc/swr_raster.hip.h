@@ -1,24 +1,10 @@
-// swr_raster.hip.h -- per-tile rasterise / depth-test / shade / blend kernel for gfx950.
+// swr_raster.hip.h -- pieces shared by the raster kernels (arguments, Interpolate + fragment programs) and the small
+// utility kernels.  The raster kernels themselves are k_cover / k_raster_c in swr_raster_c.hip.h.
 //
-// Reference path restated here (file:line under the C# repo):
-//   RasterizeTriangle tile loop   Rasterizer.cs:462-538
-//   GetDepthTestFunction          Rasterizer.cs:543-559
-//   Interpolate / InterpolateData Rasterizer.cs:566-707
-//   Renderer.FragmentShader       Renderer.cs:848-860
-//   Texture.Sample                Texture.cs:43-63
-//   Blend                         Rasterizer.cs:58-65
-//
-// Mapping: ONE WAVE OWNS ONE 16x16 TILE (the reference's lock granule).  Lane l holds the
-// four pixels x = 4*(l&3)..+3 of row y = l>>2; colour and Z of the tile stay in registers for
-// the whole triangle list, so every pixel is read at most once and written exactly once per
-// flush (clear fused into the tile init) and no atomics or locks are needed.  Triangles are
-// walked in list (= submission) order, which reproduces the serial schedule of the reference
-// for depth ties and blending.
-//
-// Exact edge values: the reference steps w0,w1,w2 incrementally in float32 from the tile's
-// bbox-clipped origin (Rasterizer.cs:481-483,527-534); 40% of the values differ from direct
-// evaluation at 4096^2, and depth is a function of them, so the add chain
-// is replayed: (y - startY) row steps, then (x - startX) column steps, each a rounded f32 add.
+// Reference code restated here (file:line under the C# repo):
+//   Interpolate / InterpolateData Rasterizer.cs:566-707   (shade_fragment)
+//   Renderer.FragmentShader       Renderer.cs:848-860     (fs_dust2; Texture.Sample, Blend, depth functions: swr_device.h)
+//   MainWindow clears / flatten   MainWindow.cs:234-240,400-436
 #pragma once
 #include "swr_device.h"
 
@@ -174,174 +160,6 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     }
     if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
     return fs_dust2(dp, f);
-}
-
-__global__ __launch_bounds__(256) void k_raster(RasterArgs a) {
-    if (a.ctrl->poison) return;
-    // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a
-    // contiguous run of tile blocks so that neighbouring tiles' triangle records hit the same L2.
-    // Bijective for any grid size; placement only affects speed.
-    const uint32_t nb = gridDim.x, b = blockIdx.x;
-    const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;
-    const uint32_t blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + kk;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bx = (int)(blk % (uint32_t)a.blocks_x), by = (int)(blk / (uint32_t)a.blocks_x);
-    const int tx = bx * 2 + (wave & 1);
-    const int ty_local = by * 2 + (wave >> 1);
-    const int ty = a.fp.band_ty0 + ty_local;
-    if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
-    const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
-    const uint32_t n = a.tile_count[tile];
-    if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
-    const uint32_t start = a.tile_start[tile];
-
-    const int W = a.fp.width, H = a.fp.height;
-    const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
-    const int row = lane >> 2, quad = lane & 3;
-    const int py = y0 + row;
-    const int pxb = x0 + quad * 4;               // first of this lane's four pixels
-    const int tile_end_x = min(x0 + SWR_TILE - 1, W - 1), tile_end_y = min(y0 + SWR_TILE - 1, H - 1);
-    const size_t rowbase = (size_t)(py - a.fp.band_y0) * (size_t)W;
-
-    float4 col[4];
-    float z[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool inb = (pxb + j) < W && py < H;
-        if (a.clear_color_on) col[j] = make_float4(a.clear_rgba[0], a.clear_rgba[1], a.clear_rgba[2], a.clear_rgba[3]);
-        else col[j] = inb ? a.color[rowbase + pxb + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.clear_depth_on) z[j] = SWR_FLOAT_MINVALUE;
-        else z[j] = inb ? a.depth[rowbase + pxb + j] : SWR_FLOAT_MINVALUE;
-    }
-    unsigned n_tested = 0, n_shaded = 0, n_written = 0;
-
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.tile_list[start + i]);
-        const TriRec* __restrict__ rp = a.recs + slot;
-        const float s0x = rp->sx[0], s1x = rp->sx[1], s2x = rp->sx[2];
-        const float s0y = rp->sy[0], s1y = rp->sy[1], s2y = rp->sy[2];
-        const uint32_t bbx = rp->bbox_x, bby = rp->bbox_y;
-        const int minX = (int)(bbx & 0xffffu), maxX = (int)(bbx >> 16);
-        const int minY = (int)(bby & 0xffffu), maxY = (int)(bby >> 16);
-
-        const int startX = max(minX, x0), endX = min(maxX, tile_end_x);        // :471-474
-        const int startY = max(minY, y0), endY = min(maxY, tile_end_y);
-        if (startX > endX || startY > endY) continue;                          // :476
-
-        const float a01 = s0y - s1y, b01 = s1x - s0x;                          // :445-447
-        const float a12 = s1y - s2y, b12 = s2x - s1x;
-        const float a20 = s2y - s0y, b20 = s0x - s2x;
-        const float fsx = (float)startX, fsy = (float)startY;
-        float w0 = a12 * (fsx - s1x) + b12 * (fsy - s1y);                      // :481-483
-        float w1 = a20 * (fsx - s2x) + b20 * (fsy - s2y);
-        float w2 = a01 * (fsx - s0x) + b01 * (fsy - s0y);
-
-        // row chain: wRow += b, (py - startY) times  (:532-534)
-        const int nrow = py - startY;
-        const int nrow_max = endY - startY;
-        for (int k = 0; k < nrow_max; ++k) {
-            if (k < nrow) { w0 += b12; w1 += b20; w2 += b01; }
-        }
-        // column chain up to this lane's first pixel: w += a, (pxb - startX) times  (:527-529)
-        const int npre = pxb - startX;
-        const int npre_max = min(12, endX - startX);
-        for (int k = 0; k < npre_max; ++k) {
-            if (k < npre) { w0 += a12; w1 += a20; w2 += a01; }
-        }
-        const bool rowok = py >= startY && py <= endY;
-        bool inside[4];
-        float e0[4], e1[4], e2[4];
-        bool any_inside = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int px = pxb + j;
-            e0[j] = w0; e1[j] = w1; e2[j] = w2;
-            const bool valid = rowok && px >= startX && px <= endX;
-            inside[j] = valid && ((w0 >= 0 && w1 >= 0 && w2 >= 0) || (w0 <= 0 && w1 <= 0 && w2 <= 0));   // :493-494
-            any_inside = any_inside || inside[j];
-            // x + (-0.0f) == x for every x, so lanes left of startX keep the row value unchanged
-            const bool step = px >= startX;
-            w0 += step ? a12 : -0.0f; w1 += step ? a20 : -0.0f; w2 += step ? a01 : -0.0f;
-        }
-        if (!__any(any_inside)) continue;
-
-        const float d0 = rp->depth[0], d1 = rp->depth[1], d2 = rp->depth[2];
-        const float inv_area = rp->inv_area;
-        const uint32_t dflags = rp->draw_flags;
-        const DrawParams* __restrict__ dp = a.draws + (dflags & SWR_DRAW_MASK);
-        const bool interp = (dflags >> 31) != 0u;
-        const int program = dp->program, depth_test = dp->depth_test, blend_mode = dp->blend;
-        const VOut* __restrict__ A = a.vout + rp->vref[0];
-        const VOut* __restrict__ B = a.vout + rp->vref[1];
-        const VOut* __restrict__ C = a.vout + rp->vref[2];
-
-        bool pass[4], alpha_ok[4];
-        float dep[4];
-        float4 src[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            pass[j] = false; alpha_ok[j] = false; dep[j] = 0.0f;
-            src[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (inside[j]) {
-                const float w0f = e0[j] * inv_area, w1f = e1[j] * inv_area, w2f = e2[j] * inv_area;   // :498-500
-                const float d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                     // :502
-                dep[j] = d;
-                if (depth_func(depth_test, d, z[j])) {                                                // :505
-                    pass[j] = true;
-                    src[j] = shade_fragment(dp, program, interp, A, B, C, w0f, w1f, w2f);             // :507-509
-                    alpha_ok[j] = src[j].w > 0.0f;                                                    // :511
-                }
-            }
-        }
-
-        if (blend_mode == SWR_BLEND_NONE) {
-            // canEarlyOut (:520-523): the first fragment of a row (within this tile) that passes depth
-            // but fails alpha ends the row: nothing to its right is visited.
-            int first_fail = 4;
-#pragma unroll
-            for (int j = 3; j >= 0; --j) if (pass[j] && !alpha_ok[j]) first_fail = j;
-            const unsigned long long fm = __ballot(first_fail < 4);
-            const unsigned rowbits = (unsigned)(fm >> (row * 4)) & 0xfu;
-            const bool killed_by_left = (rowbits & ((1u << quad) - 1u)) != 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (killed_by_left || j > first_fail) { inside[j] = false; pass[j] = false; alpha_ok[j] = false; }
-            }
-        }
-
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            n_tested += inside[j] ? 1u : 0u;
-            n_shaded += pass[j] ? 1u : 0u;
-            if (pass[j] && alpha_ok[j]) {
-                ++n_written;
-                col[j] = blend(src[j], col[j], blend_mode);                    // :513-515
-                if (depth_test != SWR_DEPTH_DISABLED) z[j] = dep[j];           // :517-518
-            }
-        }
-    }
-
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool inb = (pxb + j) < W && py < H;
-        if (inb) {
-            a.color[rowbase + pxb + j] = col[j];
-            a.depth[rowbase + pxb + j] = z[j];
-        }
-    }
-
-    // per-tile fragment counters: plain accumulate (this wave owns the tile)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_tested += (unsigned)__shfl_xor((int)n_tested, off);
-        n_shaded += (unsigned)__shfl_xor((int)n_shaded, off);
-        n_written += (unsigned)__shfl_xor((int)n_written, off);
-    }
-    if (lane == 0 && n > 0) {
-        uint32_t* ts = a.tile_stats + 3u * tile;
-        ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
-    }
 }
 
 // ---- small utility kernels -------------------------------------------------------------------

@@ -174,7 +174,8 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 #endif
 // PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
 // the switches fold away); -1 = read them from the draw at run time.
-template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1>
+// EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
+template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
 __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
     __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
@@ -225,6 +226,8 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
         L.owner[p] = 0xffffffffu;
     }
     unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+    uint32_t carry_key = 0xffffffffu;      // EARLYOUT: (pair, row) of the previous chunk's last fragment ...
+    bool carry_dead = false;               // ... and whether that row segment has already hit its `break`
 #ifdef SWR_DEBUG_COUNTERS
     unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0;
 #endif
@@ -318,6 +321,9 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
+            bool e_pass = false, e_alpha = false;          // EARLYOUT: results held until the row kills are known
+            float e_d = 0.0f;
+            float4 e_src = make_float4(0.f, 0.f, 0.f, 0.f);
             if (act) {
                 const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
                 const float d0 = f1.z, d1 = f1.w, d2 = f2.x, inv_area = f2.y;
@@ -346,17 +352,67 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
                     w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }
-                if (depth_func(f_dt, d, L.z[pix])) {                                                       // :505 / :318
-                    ++n_shaded;
-                    const float4 src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                if (!EARLYOUT) {
+                    if (depth_func(f_dt, d, L.z[pix])) {                                                   // :505 / :318
+                        ++n_shaded;
+                        const float4 src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                                                                a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
+                                                                a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509 / :321-323
+                        // triangles: W > 0 (:511); lines: W != 0 (:325)
+                        if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
+                            const float4 dst = L.col[pix];
+                            L.col[pix] = blend(src, dst, f_blend);                                         // :513-515
+                            if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = d;                                  // :517-518
+                            ++n_written;
+                        }
+                    }
+                } else {
+                    e_d = d;
+                    e_pass = depth_func(f_dt, d, L.z[pix]);
+                    if (e_pass) {
+                        e_src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
                                                             a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
-                                                            a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509 / :321-323
-                    // triangles: W > 0 (:511); lines: W != 0 (:325)
-                    if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
-                        const float4 dst = L.col[pix];
-                        L.col[pix] = blend(src, dst, f_blend);                                             // :513-515
-                        if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = d;                                      // :517-518
-                        ++n_written;
+                                                            a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);
+                        e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
+                    }
+                }
+            }
+            if (EARLYOUT) {
+                // canEarlyOut (Rasterizer.cs:430,520-523): under BlendMode.None the first fragment of a row (within this
+                // triangle and tile) that passes depth but fails alpha ends the row -- nothing to its right is visited.
+                // Fragments of one (pair, row) are consecutive in the stream, so inside a chunk that is a segmented
+                // "any failure to my left" over lanes; a segment cut by the chunk boundary carries its state over.
+                bool killed = false;
+                const bool none = f_blend == SWR_BLEND_NONE;                       // uniform: a chunk holds one draw
+                const uint32_t key = ((base + (uint32_t)t) << 4) | (uint32_t)(pix >> 4);
+                if (none) {
+                    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+                    const bool head = act && (lane == 0 || key != prev);
+                    const unsigned long long H = __ballot(head);
+                    const unsigned long long F = __ballot(act && e_pass && !e_alpha);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    const unsigned long long hm = H & (below | (1ull << lane));
+                    const int headlane = hm ? 63 - __clzll((long long)hm) : 0;
+                    const unsigned long long seg_below = below & ~((1ull << headlane) - 1ull);
+                    killed = act && (F & seg_below) != 0ull;
+                    if (act && headlane == 0 && carry_dead && key == carry_key) killed = true;
+                    const bool dead_after = killed || (act && e_pass && !e_alpha);
+                    carry_key = (uint32_t)__shfl((int)key, cut - 1);
+                    carry_dead = __shfl((int)dead_after, cut - 1) != 0;
+                } else {
+                    carry_dead = false;
+                }
+                if (act) {
+                    if (killed) {
+                        --n_tested;                                                // never visited by the reference
+                    } else if (e_pass) {
+                        ++n_shaded;
+                        if (e_alpha) {
+                            const float4 dst = L.col[pix];
+                            L.col[pix] = blend(e_src, dst, f_blend);
+                            if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = e_d;
+                            ++n_written;
+                        }
                     }
                 }
             }

@@ -180,3 +180,18 @@ def _random_scene(seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_randomised_scenes(device, seed):
     run_both(device, _random_scene(1000 + seed))
+
+
+@pytest.mark.parametrize("seed,depth_test", [(71, DepthTest.LessEqual), (72, DepthTest.Always), (73, DepthTest.Disabled), (74, DepthTest.Greater)])
+def test_blend_none_early_out_with_alpha_gradients(device, seed, depth_test):
+    """BlendMode.None row early-out (Rasterizer.cs:520-523) with alpha varying ACROSS each triangle (vertex alphas in
+    [-0.6, 1]): rows die part-way through, segments straddle the 64-fragment chunks of the stream kernel, and small
+    triangles in front shift their alignment."""
+    rng = np.random.default_rng(seed)
+    s = scenes.cfg2(200, 136, 260, seed=seed, min_area=4.0, max_area=30000.0)
+    d = s.draws[0]
+    d.vertices["color"][:, 3] = rng.uniform(-0.6, 1.0, d.vertices.shape[0]).astype(np.float32)
+    d.blend = BlendMode.None_
+    d.depth_test = depth_test
+    s.name = f"none_gradient_{seed}"
+    run_both(device, s)
