@@ -1,6 +1,5 @@
 // swr_raster_c.hip.h -- k_cover + k_raster_c: coverage masks per (triangle, tile) pair, then a per-tile
-// fragment-stream kernel.  Same contract and arithmetic as k_raster (swr_raster.hip.h; reference
-// Rasterizer.cs:462-538); this is the fast path for every blend mode except None.
+// fragment-stream kernel: the raster path (reference Rasterizer.cs:462-538 and, in wireframe mode, :232-340).
 //
 // k_cover   -- ONE LANE PER (triangle, tile) PAIR over the whole frame (pairs are the entries of the sorted
 //   tile lists, so waves are fully packed regardless of how few triangles a tile has).  Each lane walks the
