@@ -146,6 +146,9 @@ int  swr_depth_device_ptr(swr_context* ctx, void** out);
 /* Texture(Image<Rgba32>) ctor / Dispose, Texture.cs:31-41,65-68: RGBA8 row-major, w*h*4 bytes */
 int  swr_texture_create(swr_context* ctx, const uint8_t* rgba8, int width, int height, swr_texture** out);
 int  swr_texture_destroy(swr_context* ctx, swr_texture* tex);
+/* BUILD-DEFINED extension (row N4): 0 = the reference's nearest filter (Texture.cs:43-63, default), 1 = bilinear with wrap
+ * (formula in oracle/swr_oracle.c:oswr_texture_sample_bilinear; no reference semantics).  Applies to draws recorded later. */
+int  swr_texture_set_filter(swr_context* ctx, swr_texture* tex, int bilinear);
 /* Texture.Sample, Texture.cs:43-63, batched: n uv pairs -> n RGBA float4 (runs on the GPU) */
 int  swr_texture_sample(swr_context* ctx, const swr_texture* tex, const float* uv, int n, float* out_rgba);
 /* mesh.Vertices / mesh.Indices (ModelLoader.cs:45-47): u16 indices, 3 per triangle; an index >= n_vertices

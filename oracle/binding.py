@@ -59,6 +59,8 @@ def load(fma: bool = False) -> C.CDLL:
     lib.oswr_get_stats.restype = None; lib.oswr_get_stats.argtypes = [P, C.POINTER(OStats)]
     lib.oswr_reset_stats.restype = None; lib.oswr_reset_stats.argtypes = [P]
     lib.oswr_texture_sample.restype = None; lib.oswr_texture_sample.argtypes = [P, I, I, P, P]
+    lib.oswr_texture_sample_bilinear.restype = None; lib.oswr_texture_sample_bilinear.argtypes = [P, I, I, P, P]
+    lib.oswr_set_texture_filter.restype = None; lib.oswr_set_texture_filter.argtypes = [P, I]
     lib.oswr_interpolate.restype = None
     lib.oswr_interpolate.argtypes = [C.POINTER(OVertexOutput)] * 3 + [F, F, F, I, C.POINTER(OVertexOutput)]
     lib.oswr_lerp.restype = None
@@ -142,9 +144,13 @@ class OracleRenderer:
                                          m.ctypes.data, vw.ctypes.data, p.ctypes.data, int(program), uptr,
                                          tex_ptr, tw, th, int(cull), int(depth_test), int(blend))
 
+    def set_texture_filter(self, bilinear: bool):
+        self.lib.oswr_set_texture_filter(self.ctx, 1 if bilinear else 0)
+
     def render_scene(self, scene, debug_mode=0):
         """RenderScene of Renderer.cs:404-419 for a softwarerenderer_amd.scenes.Scene; returns copies (color, depth)."""
         self.set_state(scene.near_clip, scene.far_clip, debug_mode)
+        self.set_texture_filter(getattr(scene, "bilinear", False))
         if scene.clear_depth:
             self.clear_depth()
         if scene.clear_color is not None:

@@ -38,6 +38,7 @@ struct oswr_context {
     float* depth;   /* float[]  DepthBuffer, MainWindow.cs:31 */
     float near_clip, far_clip;  /* Rasterizer.cs:20-21 */
     int debug_mode;             /* Rasterizer.cs:22 */
+    int tex_bilinear;           /* build-defined extension: bilinear instead of the reference's nearest filter */
     int n_threads;
     int tiles_x, tiles_y;       /* Rasterizer.cs:55 */
     atomic_flag* tile_locks;    /* Rasterizer.cs:54 (monitor per tile) */
@@ -254,6 +255,29 @@ void oswr_texture_sample(const uint8_t* rgba8, int w, int h, const float uv[2], 
     out[2] = (float)p[2] * inv255; out[3] = (float)p[3] * inv255;
 }
 
+/* BUILD-DEFINED bilinear filter (row N4; the reference samples nearest).  Texel centres at (i + 0.5) / size, wrap
+ * addressing, float32 throughout, lerps as a*(1-t) + b*t (unfused):
+ *   x = u*W - 0.5, y = v*H - 0.5; x0 = floor(x), fx = x - x0 (same in y); taps wrap((int)x0), wrap((int)x0 + 1);
+ *   out = lerp(lerp(c00, c10, fx), lerp(c01, c11, fx), fy), each c = byte * (1f/255f). */
+static inline int wrap_idx(int i, int n) { int r = i % n; return r < 0 ? r + n : r; }
+void oswr_texture_sample_bilinear(const uint8_t* rgba8, int w, int h, const float uv[2], float out[4]) {
+    float x = uv[0] * (float)w - 0.5f, y = uv[1] * (float)h - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int ix0 = wrap_idx(f2i(x0), w), iy0 = wrap_idx(f2i(y0), h);
+    int ix1 = ix0 + 1 == w ? 0 : ix0 + 1, iy1 = iy0 + 1 == h ? 0 : iy0 + 1;
+    const float inv255 = 1.0f / 255.0f;
+    const uint8_t* p00 = rgba8 + 4 * ((size_t)iy0 * w + ix0); const uint8_t* p10 = rgba8 + 4 * ((size_t)iy0 * w + ix1);
+    const uint8_t* p01 = rgba8 + 4 * ((size_t)iy1 * w + ix0); const uint8_t* p11 = rgba8 + 4 * ((size_t)iy1 * w + ix1);
+    for (int c = 0; c < 4; ++c) {
+        float c00 = (float)p00[c] * inv255, c10 = (float)p10[c] * inv255, c01 = (float)p01[c] * inv255, c11 = (float)p11[c] * inv255;
+        float top = c00 * (1.0f - fx) + c10 * fx;
+        float bot = c01 * (1.0f - fx) + c11 * fx;
+        out[c] = top * (1.0f - fy) + bot * fy;
+    }
+}
+void oswr_set_texture_filter(oswr_context* c, int bilinear) { c->tex_bilinear = bilinear; }
+
 /* ---------- Renderer.VertexShader, Renderer.cs:830-846 ---------- */
 void oswr_vertex_shader(const oswr_vertex_input* in, const float model[16], const float view[16],
                         const float projection[16], int program, oswr_vertex_output* out) {
@@ -364,7 +388,7 @@ static void fs_dust2(const oswr_uniforms* u, const oswr_vertex_output* in,
     float neg_l[3] = { -u->light_direction[0], -u->light_direction[1], -u->light_direction[2] };
     float diffuse = mathf_max(0.25f, vec3_dot(in->world_normal, neg_l));          /* :851 */
     float tc[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-    if (tex) oswr_texture_sample(tex, tw, th, in->texcoord, tc);                     /* :852 */
+    if (tex) { if (th < 0) oswr_texture_sample_bilinear(tex, tw, -th, in->texcoord, tc); else oswr_texture_sample(tex, tw, th, in->texcoord, tc); }   /* :852; th < 0 encodes the build-defined bilinear filter */
     float base[4];
     for (int i = 0; i < 4; ++i) base[i] = in->color[i] * tc[i];                      /* :853 */
     float depth = in->clip[2];                                                       /* :854 */
@@ -386,7 +410,7 @@ static void fs_dust2(const oswr_uniforms* u, const oswr_vertex_output* in,
 static void fs_phong4(const oswr_uniforms* u, const oswr_vertex_output* in,
                       const uint8_t* tex, int tw, int th, float out[4]) {
     float tc[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
-    if (tex) oswr_texture_sample(tex, tw, th, in->texcoord, tc);
+    if (tex) { if (th < 0) oswr_texture_sample_bilinear(tex, tw, -th, in->texcoord, tc); else oswr_texture_sample(tex, tw, th, in->texcoord, tc); }
     float base[4];
     for (int i = 0; i < 4; ++i) base[i] = in->color[i] * tc[i];
     const float* N = in->world_normal;
@@ -708,7 +732,7 @@ int oswr_render_mesh(oswr_context* c,
     draw_state ds;
     memset(&ds, 0, sizeof(ds));
     ds.ctx = c; ds.program = program; ds.uniforms = uniforms;
-    ds.tex = (tex && tw > 0 && th > 0) ? tex : NULL; ds.tw = tw; ds.th = th;
+    ds.tex = (tex && tw > 0 && th > 0) ? tex : NULL; ds.tw = tw; ds.th = c->tex_bilinear ? -th : th;
     ds.cull = cull_mode; ds.depth_test = depth_test; ds.blend = blend_mode;
 
     if (c->n_threads <= 1) {

@@ -127,6 +127,9 @@ void  oswr_interpolate(const oswr_vertex_output* a, const oswr_vertex_output* b,
 void  oswr_lerp(const oswr_vertex_output* a, const oswr_vertex_output* b, float t, int interpolate,
                 oswr_vertex_output* out);
 void  oswr_texture_sample(const uint8_t* rgba8, int w, int h, const float uv[2], float out[4]);
+/* BUILD-DEFINED bilinear filter with wrap (no reference semantics: Texture.Sample is nearest) */
+void  oswr_texture_sample_bilinear(const uint8_t* rgba8, int w, int h, const float uv[2], float out[4]);
+void  oswr_set_texture_filter(oswr_context* c, int bilinear);   /* applies to the textures of subsequent oswr_render_mesh calls */
 int   oswr_fragment_shader(int program, const oswr_uniforms* u, const oswr_vertex_output* in,
                            const uint8_t* tex, int tw, int th, float out[4]);
 void  oswr_blend(const float src[4], const float dst[4], int mode, float out[4]);

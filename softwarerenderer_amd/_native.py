@@ -63,7 +63,7 @@ EXPORTS = [
     "swr_abi_version", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band",
     "swr_bind_framebuffer", "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel",
     "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_upload", "swr_color_device_ptr",
-    "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_sample",
+    "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
     "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters",
@@ -106,6 +106,7 @@ def load() -> C.CDLL:
         "swr_depth_device_ptr": (I, [P, C.POINTER(P)]),
         "swr_texture_create": (I, [P, P, I, I, C.POINTER(P)]),
         "swr_texture_destroy": (I, [P, P]),
+        "swr_texture_set_filter": (I, [P, P, I]),
         "swr_texture_sample": (I, [P, P, P, I, P]),
         "swr_mesh_create": (I, [P, P, I, P, I, C.POINTER(P)]),
         "swr_mesh_destroy": (I, [P, P]),

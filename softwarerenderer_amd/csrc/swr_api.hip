@@ -35,6 +35,7 @@ struct swr_mesh {
 struct swr_texture {
     uint8_t* d_rgba = nullptr;
     int w = 0, h = 0;
+    bool bilinear = false;                    // build-defined extension; the reference's Texture.Sample is nearest
 };
 
 namespace {
@@ -613,7 +614,7 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     if (u) d.p.u = *u;
     d.p.verts = mesh->d_verts; d.p.idx = mesh->d_idx;
     d.p.tex = tex ? tex->d_rgba : nullptr;
-    d.p.tex_w = tex ? tex->w : 0; d.p.tex_h = tex ? tex->h : 0;
+    d.p.tex_w = tex ? tex->w : 0; d.p.tex_h = tex ? (tex->bilinear ? -tex->h : tex->h) : 0;
     d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
     d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
     d.mesh = mesh;
@@ -884,6 +885,13 @@ int swr_texture_create(swr_context* c, const uint8_t* rgba8, int w, int h, swr_t
         return e == hipErrorOutOfMemory ? SWR_ERR_OOM : SWR_ERR_HIP;
     }
     *out = t;
+    return SWR_OK;
+}
+
+int swr_texture_set_filter(swr_context* c, swr_texture* t, int bilinear) {
+    SWR_ENTER(c);
+    if (!t) return fail(c, SWR_ERR_INVALID_ARG, "texture is null");
+    t->bilinear = bilinear != 0;          // read when a draw is recorded
     return SWR_OK;
 }
 

@@ -56,7 +56,7 @@ struct DrawParams {
     const swr_vertex* verts;
     const uint16_t* idx;
     const uint8_t* tex;
-    int tex_w, tex_h;
+    int tex_w, tex_h;          // tex_h < 0: build-defined bilinear filter on a texture of height -tex_h (reference = nearest)
     int program, cull, depth_test, blend;
     uint32_t n_verts, n_tris;
     uint32_t vert_base;     // first VOut of this draw
@@ -242,6 +242,35 @@ __device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex
     o.z = (float)((p >> 16) & 0xffu) * inv255;
     o.w = (float)(p >> 24) * inv255;
     return o;
+}
+
+// BUILD-DEFINED bilinear filter with wrap (row N4; no reference semantics -- the formula is stated in
+// oracle/swr_oracle.c:oswr_texture_sample_bilinear and reproduced operation for operation)
+__device__ __forceinline__ float4 texture_sample_bilinear(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
+    const float x = tu * (float)w - 0.5f, y = tv * (float)h - 0.5f;
+    const float x0 = floorf(x), y0 = floorf(y);
+    const float fx = x - x0, fy = y - y0;
+    int ix0 = f2i(x0) % w; if (ix0 < 0) ix0 += w;
+    int iy0 = f2i(y0) % h; if (iy0 < 0) iy0 += h;
+    const int ix1 = ix0 + 1 == w ? 0 : ix0 + 1, iy1 = iy0 + 1 == h ? 0 : iy0 + 1;
+    const uint32_t p00 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy0 * (size_t)w + (size_t)ix0));
+    const uint32_t p10 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy0 * (size_t)w + (size_t)ix1));
+    const uint32_t p01 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy1 * (size_t)w + (size_t)ix0));
+    const uint32_t p11 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy1 * (size_t)w + (size_t)ix1));
+    const float inv255 = 1.0f / 255.0f;
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float c00 = (float)((p00 >> (8 * c)) & 0xffu) * inv255, c10 = (float)((p10 >> (8 * c)) & 0xffu) * inv255;
+        const float c01 = (float)((p01 >> (8 * c)) & 0xffu) * inv255, c11 = (float)((p11 >> (8 * c)) & 0xffu) * inv255;
+        const float top = c00 * (1.0f - fx) + c10 * fx;
+        const float bot = c01 * (1.0f - fx) + c11 * fx;
+        o[c] = top * (1.0f - fy) + bot * fy;
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ float4 texture_fetch(const uint8_t* __restrict__ tex, int w, int h_signed, float tu, float tv) {
+    return h_signed < 0 ? texture_sample_bilinear(tex, w, -h_signed, tu, tv) : texture_sample(tex, w, h_signed, tu, tv);
 }
 
 }  // namespace swr

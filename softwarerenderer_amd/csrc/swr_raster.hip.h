@@ -43,7 +43,7 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (dp->tex) tc = texture_sample(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
     float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
     float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
     fog = (fog * fog) * (3.0f - 2.0f * fog);
@@ -60,7 +60,7 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
 __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, const Frag& f) {
     const swr_uniforms& u = dp->u;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (dp->tex) tc = texture_sample(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
     float base[4] = { f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w };
     float Vd[3] = { u.camera_position[0] - f.wpos[0], u.camera_position[1] - f.wpos[1], u.camera_position[2] - f.wpos[2] };
     float vl = sqrtf(dot3(Vd[0], Vd[1], Vd[2], Vd[0], Vd[1], Vd[2]));

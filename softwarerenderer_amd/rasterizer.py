@@ -176,6 +176,10 @@ class Texture:
         self._dev._ck(self._dev._lib.swr_texture_sample(self._dev._ctx, self._h, flat.ctypes.data, flat.shape[0], out.ctypes.data))
         return out.reshape(a.shape[:-1] + (4,))
 
+    def SetBilinear(self, on: bool):
+        """Build-defined extension (the reference samples nearest): bilinear filter with wrap for later draws."""
+        self._dev._ck(self._dev._lib.swr_texture_set_filter(self._dev._ctx, self._h, 1 if on else 0))
+
     def Dispose(self):
         if self._h:
             self._dev._ck(self._dev._lib.swr_texture_destroy(self._dev._ctx, self._h))

@@ -46,6 +46,7 @@ class Scene:
     clear_depth: bool = True
     near_clip: float = 0.1
     far_clip: float = 1000.0
+    bilinear: bool = False                                       # build-defined texture filter extension (reference = nearest)
 
     @property
     def n_triangles(self) -> int:
@@ -283,6 +284,9 @@ class SceneRenderer:
         self.dev, self.scene = device, scene
         self.window = window or MainWindow(device, scene.width, scene.height)
         self.textures = [Texture(device, t) for t in scene.textures]
+        if scene.bilinear:
+            for t in self.textures:
+                t.SetBilinear(True)
         self.programs, self.meshes = [], []
         for d in scene.draws:
             tex = self.textures[d.texture] if d.texture is not None else None

@@ -195,3 +195,15 @@ def test_blend_none_early_out_with_alpha_gradients(device, seed, depth_test):
     d.depth_test = depth_test
     s.name = f"none_gradient_{seed}"
     run_both(device, s)
+
+
+def test_bilinear_extension_matches_its_oracle_definition(device):
+    """Opt-in bilinear filter (row N4): build-defined, no reference semantics -- GPU and oracle implement one formula."""
+    s = scenes.cfg3(384, 320, (3, 3), (20, 14), tex_size=37, seed=81)
+    s.bilinear = True
+    s.name += "_bilinear"
+    run_both(device, s)
+    near = scenes.cfg3(384, 320, (3, 3), (20, 14), tex_size=37, seed=81)
+    c_near, _, _ = render_oracle(near)
+    c_bil, _, _ = render_oracle(s)
+    assert not np.array_equal(c_near, c_bil)          # the filter really changes the image
