@@ -203,6 +203,27 @@ def cfg5(**kw) -> Scene:
     return s
 
 
+def from_model(model, width=640, height=480, eye=None, seed=3, tex_size=64, program=Program.Dust2LambertFog,
+               name="model") -> Scene:
+    """One frame of Renderer.RenderDust2 (Renderer.cs:422-468) over a loaded `modelloader.Model`: one RenderMesh per
+    mesh in order, ModelMatrix = CreateScale(0.5), CullMode.Back / LessEqual / Alpha.  Image decoding (ImageSharp in the
+    reference) is out of scope, so each mesh gets a procedural RGBA8 texture instead of its material's file."""
+    proj = _perspective(width, height)
+    mm = hm.create_scale(0.5)
+    allp = np.concatenate([m.Vertices["position"] for m in model.Meshes]).astype(np.float64) * 0.5
+    lo, hi = allp.min(axis=0), allp.max(axis=0)
+    centre, radius = (lo + hi) / 2, float(np.linalg.norm(hi - lo)) / 2 + 1e-3
+    if eye is None:
+        eye = centre + np.array([0.35, 0.3, 1.0]) * radius * 1.6
+    view = hm.create_look_at(tuple(float(v) for v in eye), tuple(float(v) for v in centre), (0.0, 1.0, 0.0))
+    uni = default_uniforms()
+    uni.fog_start, uni.fog_end = radius * 2.0, radius * 6.0
+    textures = [random_texture(tex_size, seed + i) for i in range(len(model.Meshes))]
+    draws = [Draw(m.Vertices, m.Indices, mm, view, proj, program=program, uniforms=uni, texture=i)
+             for i, m in enumerate(model.Meshes)]
+    return Scene(name, width, height, draws, textures=textures)
+
+
 # ------------------------------------------------------------------------------------- edge-case scenes
 def near_clip_scene(width=320, height=200, n_tris=300, seed=7, program=Program.Dust2LambertFog) -> Scene:
     """Triangles straddling the camera plane (some W<=0): exercises ClipTriangleAgainstNearPlane."""

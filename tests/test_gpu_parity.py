@@ -207,3 +207,41 @@ def test_bilinear_extension_matches_its_oracle_definition(device):
     c_near, _, _ = render_oracle(near)
     c_bil, _, _ = render_oracle(s)
     assert not np.array_equal(c_near, c_bil)          # the filter really changes the image
+
+
+def test_loaded_gltf_model_renders_like_the_oracle(device, tmp_path):
+    """Row N4 end to end: glTF -> modelloader.Model -> one RenderDust2-style frame, GPU against the oracle."""
+    import json
+    from softwarerenderer_amd.modelloader import Model
+    Model._model_cache.clear()
+    nu, nv = 24, 16
+    u, v = np.meshgrid(np.linspace(0, 2 * np.pi, nu + 1), np.linspace(0.05, np.pi - 0.05, nv + 1))
+    nrm = np.stack([np.sin(v) * np.cos(u), np.cos(v), np.sin(v) * np.sin(u)], axis=-1).reshape(-1, 3).astype(np.float32)
+    pos = (nrm * np.float32(2.0)).astype(np.float32)
+    uv = np.stack([u / (2 * np.pi) * 3, v / np.pi * 2], axis=-1).reshape(-1, 2).astype(np.float32)
+    idx = []
+    for j in range(nv):
+        for i in range(nu):
+            a = j * (nu + 1) + i
+            idx += [a, a + nu + 1, a + 1, a + 1, a + nu + 1, a + nu + 2]
+    blob = pos.tobytes() + nrm.tobytes() + uv.tobytes() + np.asarray(idx, dtype=np.uint16).tobytes()
+    (tmp_path / "s.bin").write_bytes(blob)
+    n = pos.shape[0]
+    doc = {"asset": {"version": "2.0"}, "scenes": [{"nodes": [0, 1]}],
+           "nodes": [{"mesh": 0, "translation": [-1.5, 0, 0], "scale": [1, 1.3, 1]},
+                     {"mesh": 0, "translation": [1.5, 0.5, -1], "rotation": [0.0, 0.3826834, 0.0, 0.9238795]}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3}]}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": n, "type": "VEC3"},
+                         {"bufferView": 1, "componentType": 5126, "count": n, "type": "VEC3"},
+                         {"bufferView": 2, "componentType": 5126, "count": n, "type": "VEC2"},
+                         {"bufferView": 3, "componentType": 5123, "count": len(idx), "type": "SCALAR"}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": n * 12},
+                           {"buffer": 0, "byteOffset": n * 12, "byteLength": n * 12},
+                           {"buffer": 0, "byteOffset": n * 24, "byteLength": n * 8},
+                           {"buffer": 0, "byteOffset": n * 32, "byteLength": len(idx) * 2}],
+           "buffers": [{"byteLength": len(blob), "uri": "s.bin"}]}
+    (tmp_path / "s.gltf").write_text(json.dumps(doc))
+    model = Model().LoadModel(str(tmp_path / "s.gltf"))
+    assert len(model.Meshes) == 2 and all(m.Indices.size == len(idx) for m in model.Meshes)
+    s = scenes.from_model(model, 400, 300, name="gltf_spheres")
+    run_both(device, s)
