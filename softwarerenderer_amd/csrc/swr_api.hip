@@ -108,6 +108,7 @@ struct swr_context {
     DevBuf d_pair_tile, d_masks, d_pcounts, d_ctrl;
     uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
+    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32: heaviest-first raster order
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
@@ -301,6 +302,9 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     int rc;
     const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
     unsigned long long* d_total = c->d_total.as<unsigned long long>();
+    uint32_t* tile_work = c->d_order.as<uint32_t>();
+    uint32_t* tile_order = tile_work + n_tiles;
+    uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
     BinArgs ba;
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
     ba.recs = c->d_recs.as<TriRec>();
@@ -329,7 +333,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count,
                            c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
                            cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
-                           mode == MODE_ASYNC ? 1 : 0);
+                           mode == MODE_ASYNC ? 1 : 0, tile_work, order_hist);
         SWR_HIP(c, hipGetLastError());
     }
     uint32_t cover_items = ba.list_capacity;          // async: grid covers the whole capacity, lanes beyond the total exit
@@ -376,11 +380,22 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.masks = c->d_masks.as<uint4>();
         ca.counts = c->d_pcounts.as<uint16_t>();
         ca.n_pairs = d_total;
+        ca.tile_work = tile_work;
         ca.ctrl = ctrl;
         ca.fp = frame_params(c);
         ca.fp.near_clip = b.near_clip;
         if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
         else hipLaunchKernelGGL(k_cover<false>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
+        SWR_HIP(c, hipGetLastError());
+    }
+    {
+        ScopedSpan sp(c, ST_SORT);
+        const unsigned ob = (n_tiles + 255u) / 256u;
+        hipLaunchKernelGGL(k_tile_hist, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
+                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), n_tiles, order_hist, ctrl);
+        hipLaunchKernelGGL(k_tile_place, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
+                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), n_tiles, (const uint32_t*)order_hist,
+                           order_hist + SWR_ORDER_BUCKETS, tile_order, ctrl);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -399,13 +414,11 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         memcpy(ra.clear_rgba, b.clear_rgba, 16);
         ra.clear_color_on = cc ? 1 : 0;
         ra.clear_depth_on = cd ? 1 : 0;
-        ra.blocks_x = (c->tiles_x + 1) / 2;
-        ra.blocks_y = (c->band_ty1 - c->band_ty0 + 1) / 2;
+        ra.tile_order = tile_order;
         ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
         ra.ctrl = ctrl;
-        const unsigned quads = (unsigned)(ra.blocks_x * ra.blocks_y);
         {
-            const dim3 g(quads * (4u / SWR_RASTER_WPB)), t(64 * SWR_RASTER_WPB);
+            const dim3 g(n_tiles), t(64);                        // one wave per tile
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
             const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
             bool phong = false, none = false, dust2_default = true;
@@ -465,6 +478,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if ((rc = ensure(c, c->d_slot_tb, (size_t)(spt * T) * 8))) return rc;
     if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 8 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
         if ((rc = ensure(c, c->d_tile_stats, (size_t)n_tiles * 12))) return rc;
         SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
@@ -710,7 +724,7 @@ void swr_destroy(swr_context* c) {
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
     if (c->host_poison) (void)hipHostFree(c->host_poison);
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
-                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats,
+                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -11,6 +11,8 @@
 #pragma once
 #include "swr_device.h"
 
+#define SWR_ORDER_BUCKETS 256      // heaviest-first tile order: counting-sort buckets (see k_tile_place)
+
 namespace swr {
 
 struct BinArgs {
@@ -246,10 +248,14 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
                                                      uint32_t n, const unsigned long long* __restrict__ sums,
                                                      unsigned long long* __restrict__ total_out,
                                                      unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
-                                                     Counters* __restrict__ counters, int poison_on_overflow) {
+                                                     Counters* __restrict__ counters, int poison_on_overflow,
+                                                     uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order_hist) {
     __shared__ unsigned long long s_part[16];
     __shared__ unsigned long long s_wave[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // reset the per-tile work sums (k_cover adds to them) and the histogram / cursors of the tile ordering
+    if (blockIdx.x * 1024u + tid < n) tile_work[blockIdx.x * 1024u + tid] = 0u;
+    if (blockIdx.x == 0 && tid < 2u * SWR_ORDER_BUCKETS) order_hist[tid] = 0u;
     // offset of this block = sum of the earlier blocks' sums (gridDim.x <= 1024)
     const unsigned long long off = block_sum_1024(tid < blockIdx.x ? sums[tid] : 0ull, s_part);
     const uint32_t i = blockIdx.x * 1024u + tid;
@@ -280,6 +286,62 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
             atomicAdd(&counters->tile_pairs, total);        // MODE_SYNC rounds are counted by the host
         }
     }
+}
+
+// ---- heaviest-first tile order for the raster kernel ---------------------------------------------
+// One wave rasterises one tile and tiles differ a lot in work, so the launch ends with a few long tiles running on
+// an otherwise idle chip.  Workgroups are dispatched in index order as slots free up: handing out the tiles by
+// descending work (fragments counted by k_cover + a per-pair cost) makes that dispatch a longest-first schedule.
+// Counting sort over 8 buckets per octave; the order inside a bucket is arbitrary (tiles are independent).
+__device__ __forceinline__ uint32_t order_bucket(uint32_t w) {
+    if (w == 0u) return 0u;
+    const int e = 31 - __clz((int)w);
+    const uint32_t m = e >= 3 ? ((w >> (e - 3)) & 7u) : ((w << (3 - e)) & 7u);
+    return min((uint32_t)(e * 8) + m + 1u, (uint32_t)SWR_ORDER_BUCKETS - 1u);
+}
+__device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return frags + 16u * pairs; }
+
+__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
+                                                   uint32_t n, uint32_t* __restrict__ hist, const Ctrl* __restrict__ ctrl) {
+    __shared__ uint32_t s_h[SWR_ORDER_BUCKETS];
+    if (ctrl->poison) return;
+    s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) atomicAdd(&s_h[order_bucket(tile_weight(tile_work[i], tile_count[i]))], 1u);
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void k_tile_place(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
+                                                    uint32_t n, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                    uint32_t* __restrict__ order, const Ctrl* __restrict__ ctrl) {
+    __shared__ uint32_t s_suf[SWR_ORDER_BUCKETS];     // tiles in heavier buckets (descending order)
+    __shared__ uint32_t s_cnt[SWR_ORDER_BUCKETS];     // this block's tiles per bucket, then their global base
+    if (ctrl->poison) return;
+    const uint32_t t = threadIdx.x;
+    s_suf[t] = hist[t];
+    s_cnt[t] = 0u;
+    __syncthreads();
+    for (uint32_t off = 1; off < (uint32_t)SWR_ORDER_BUCKETS; off <<= 1) {       // inclusive suffix sum
+        const uint32_t v = t + off < (uint32_t)SWR_ORDER_BUCKETS ? s_suf[t + off] : 0u;
+        __syncthreads();
+        s_suf[t] += v;
+        __syncthreads();
+    }
+    const uint32_t i = blockIdx.x * 256u + t;
+    uint32_t b = 0, rank = 0;
+    if (i < n) {
+        b = order_bucket(tile_weight(tile_work[i], tile_count[i]));
+        rank = atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    // one global reservation per (block, bucket): same-address atomics with a return value are slow
+    const uint32_t mine = s_cnt[t];
+    __syncthreads();
+    if (mine) s_cnt[t] = (s_suf[t] - hist[t]) + atomicAdd(&cursor[t], mine);
+    __syncthreads();
+    if (i < n) order[s_cnt[b] + rank] = i;
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------

@@ -18,12 +18,12 @@ struct RasterArgs {
     const uint32_t* __restrict__ tile_start;
     const uint32_t* __restrict__ tile_count;
     const uint32_t* __restrict__ tile_list;
+    const uint32_t* __restrict__ tile_order;   // band-local tile index per workgroup
     float4* __restrict__ color;
     float* __restrict__ depth;
     uint32_t* __restrict__ tile_stats;     // 3 x u32 per tile: tested, shaded, written (accumulated)
     float clear_rgba[4];
     int clear_color_on, clear_depth_on;
-    int blocks_x, blocks_y;                // grid of 2x2-tile workgroups over the band
     unsigned long long* dbg;               // SWR_DEBUG_COUNTERS builds only: 8 accumulators
     const Ctrl* __restrict__ ctrl;         // poison guard (see Ctrl)
 };
@@ -43,7 +43,11 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+#ifndef SWR_ABL_NOTEX
     if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+#else
+    tc.x = f.u; tc.y = f.v;
+#endif
     float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
     float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
     fog = (fog * fog) * (3.0f - 2.0f * fog);
@@ -90,38 +94,39 @@ __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, c
     return make_float4(acc[0], acc[1], acc[2], base[3]);
 }
 
+// The varyings of one triangle's three outputs, as the fragment path reads them (VOut as four float4:
+// [0] clip  [1] color  [2] uv.xy, wn.xy  [3] wn.z, wpos.xyz).  k_raster_c stages them per pair in LDS.
+struct TriVaryings {
+    float4 a_clip, b_clip, c_clip;
+    float4 a_col, b_col, c_col;
+    float4 a_uvn, b_uvn, c_uvn;
+    float a_wnz, b_wnz, c_wnz;
+    float a_wpos[3], b_wpos[3], c_wpos[3];     // PHONG only
+};
+
 // Rasterizer.Interpolate for the varyings `program` reads, then the fragment program.
 // A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.
-// All vertex-attribute loads are issued together at the top (one memory round trip instead of one per branch:
-// with per-lane vertex pointers each dependent group costs an L2 latency).
-// PIN = true (per-lane vertex pointers): pin the loaded values where they are loaded -- hipcc otherwise sinks each
-// load into the branch that uses it and the fragment pays four or five dependent L2 round trips.
-#define SWR_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
 // PHONG = false compiles the build-defined 4-light program out (batches without such a draw): fewer live registers
-template <bool PIN = false, bool PHONG = true>
+template <bool PHONG = true>
 __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, int program, bool interp,
-                                                 const VOut* __restrict__ A, const VOut* __restrict__ B,
-                                                 const VOut* __restrict__ C, float w0f, float w1f, float w2f) {
-    const float4* __restrict__ pa = reinterpret_cast<const float4*>(A);
-    const float4* __restrict__ pb = reinterpret_cast<const float4*>(B);
-    const float4* __restrict__ pc = reinterpret_cast<const float4*>(C);
+                                                 const TriVaryings& V, float w0f, float w1f, float w2f) {
     const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
-    // VOut as four float4: [0] clip  [1] color  [2] uv.xy, wn.xy  [3] wn.z, wpos.xyz
-    float4 a_clip = pa[0], b_clip = pb[0], c_clip = pc[0];
-    float4 a_col = pa[1], b_col = pb[1], c_col = pc[1];
-    float4 a_uvn, b_uvn, c_uvn, a_nz, b_nz, c_nz;
-    if (!simple) { a_uvn = pa[2]; b_uvn = pb[2]; c_uvn = pc[2]; a_nz = pa[3]; b_nz = pb[3]; c_nz = pc[3]; }
-    if (PIN) {
-        SWR_PIN4(a_clip); SWR_PIN4(b_clip); SWR_PIN4(c_clip); SWR_PIN4(a_col); SWR_PIN4(b_col); SWR_PIN4(c_col);
-        if (!simple) { SWR_PIN4(a_uvn); SWR_PIN4(b_uvn); SWR_PIN4(c_uvn); SWR_PIN4(a_nz); SWR_PIN4(b_nz); SWR_PIN4(c_nz); }
-    }
+    const float4 a_clip = V.a_clip, b_clip = V.b_clip, c_clip = V.c_clip;
+    const float4 a_col = V.a_col, b_col = V.b_col, c_col = V.c_col;
+    const float4 a_uvn = V.a_uvn, b_uvn = V.b_uvn, c_uvn = V.c_uvn;
     if (simple && !interp) return a_col;                                                             // :622-627
 
+#ifdef SWR_ABL_NODIV
+    float ra = __fdividef(w0f, a_clip.w), rb = __fdividef(w1f, b_clip.w), rc = __fdividef(w2f, c_clip.w);
+    float inv_sum = (ra + rb) + rc;
+    float w = __fdividef(1.0f, inv_sum);
+#else
     float ra = w0f / a_clip.w;              // :576-578
     float rb = w1f / b_clip.w;
     float rc = w2f / c_clip.w;
     float inv_sum = (ra + rb) + rc;         // :579
     float w = 1.0f / inv_sum;               // :582
+#endif
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
     Frag f;
     if (interp) {
@@ -141,7 +146,7 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         // InterpolateData, Vector3 key: weighted sum with the NORMALISED weights, then renormalise (:680-688)
         float n0 = (a_uvn.z * wa + b_uvn.z * wb) + c_uvn.z * wc;
         float n1 = (a_uvn.w * wa + b_uvn.w * wb) + c_uvn.w * wc;
-        float n2 = (a_nz.x * wa + b_nz.x * wb) + c_nz.x * wc;
+        float n2 = (V.a_wnz * wa + V.b_wnz * wb) + V.c_wnz * wc;
         float len_sq = dot3(n0, n1, n2, n0, n1, n2);
         if (len_sq > 1e-6f) {
             float s = 1.0f / sqrtf(len_sq);
@@ -150,13 +155,12 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
         // Vector4 key: weighted sum only (:690-693); only PHONG_4POINT reads it
         if (PHONG) {
-        f.wpos[0] = (a_nz.y * wa + b_nz.y * wb) + c_nz.y * wc;
-        f.wpos[1] = (a_nz.z * wa + b_nz.z * wb) + c_nz.z * wc;
-        f.wpos[2] = (a_nz.w * wa + b_nz.w * wb) + c_nz.w * wc;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) f.wpos[i] = (V.a_wpos[i] * wa + V.b_wpos[i] * wb) + V.c_wpos[i] * wc;
         }
     } else {
-        f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = a_nz.x;
-        f.wpos[0] = a_nz.y; f.wpos[1] = a_nz.z; f.wpos[2] = a_nz.w;
+        f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = V.a_wnz;
+        if (PHONG) { f.wpos[0] = V.a_wpos[0]; f.wpos[1] = V.a_wpos[1]; f.wpos[2] = V.a_wpos[2]; }
     }
     if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
     return fs_dust2(dp, f);

@@ -9,7 +9,7 @@
 // k_raster_c -- one wave per 16x16 tile.  The tile's fragment stream is the concatenation, in submission
 //   order, of the set bits of its pairs' masks (row-major inside a pair = the reference's pixel order).  64
 //   consecutive fragments are taken at a time, one per lane; the chunk is cut at the first fragment whose pixel
-//   already occurs earlier in the chunk (ds_min owner election) or whose draw differs, so inside a chunk every
+//   is already claimed in the chunk (LDS bitmap election) or whose draw differs, so inside a chunk every
 //   pixel is touched once and state is uniform: depth test, Interpolate, fragment program, blend and the
 //   colour/Z update (tile-resident in LDS) are order-independent inside a chunk, and chunks run in stream order
 //   = the serial schedule of the reference (>= ties, blending, alpha-gated Z writes all exact).  Each fragment
@@ -36,6 +36,7 @@ struct CoverArgs {
     uint4* __restrict__ masks;                // 2 x uint4 per pair: row r -> bits (r & 1) * 16 .. of word r >> 1
     uint16_t* __restrict__ counts;            // popcount of the mask
     const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
+    uint32_t* __restrict__ tile_work;         // per tile: sum of the counts (raster scheduling weight)
     const Ctrl* __restrict__ ctrl;
     FrameParams fp;
 };
@@ -134,22 +135,49 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
         a.counts[p] = (uint16_t)cnt;
     }
+    // raster scheduling weight: fragments per tile.  Pairs are sorted by tile, so a wave holds a few runs of equal
+    // tiles: one atomic per run (its last lane adds the run's sum, taken from a wave prefix sum).
+    {
+        const int lane = threadIdx.x & 63;
+        const uint32_t tile = p < n_pairs ? a.pair_tile[p] : 0xffffffffu;
+        const int incl = wave_incl_scan(cnt, lane);
+        const uint32_t next_tile = (uint32_t)__shfl_down((int)tile, 1);
+        const bool run_end = lane == 63 || next_tile != tile;
+        const uint32_t prev_tile = (uint32_t)__shfl_up((int)tile, 1);
+        const unsigned long long starts = __ballot(lane == 0 || prev_tile != tile);
+        const unsigned long long upto = starts & ((2ull << lane) - 1ull);                  // run starts at or below this lane
+        const int first = 63 - __clzll((long long)upto);
+        const int before = __shfl(incl - cnt, first);                                      // prefix before the run
+        if (run_end && tile != 0xffffffffu && incl - before > 0) atomicAdd(&a.tile_work[tile], (uint32_t)(incl - before));
+    }
 }
 
-// pairs per batch: 64 fills the wave's lanes in the batch set-up; 32 halves the LDS staging so a fifth wave fits per SIMD
+// pairs per batch.  Everything a fragment needs from its triangle (the TriRec and the three outputs' varyings)
+// is staged in LDS once per batch by one lane per pair: per-fragment gathers of that data (256 B per fragment
+// through the vector L1, which is what bounded the kernel) become LDS broadcasts.
 #ifndef SWR_BATCH
-#define SWR_BATCH 32
+#define SWR_BATCH 16
 #endif
 #ifndef SWR_RASTER_MINWAVES
-#define SWR_RASTER_MINWAVES 5
+#define SWR_RASTER_MINWAVES 4
 #endif
+#define SWR_BATCH_FRAGS (SWR_BATCH * 256)      // a pair covers <= 256 pixels
+// staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
+//   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
+//   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
+//   3: row steps b12,b20,b01                  4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the
+//   output's wn.z), color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
+template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
+    static constexpr int NQ = PHONG ? 16 : 13;
     float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
     float z[256];
-    uint32_t owner[256];             // chunk duplicate election (0xffffffff when idle)
-    uint32_t mask[SWR_BATCH][8];     // batch: coverage masks
-    uint32_t slot[SWR_BATCH];        // batch: triangle slot ids
-    uint32_t pre[SWR_BATCH + 4];     // batch: exclusive prefix of covered counts, pre[SWR_BATCH] = total
+    float4 stage[NQ][SWR_BATCH];     // batch (non-empty pairs only, compacted): per-pair fragment inputs
+    uint32_t mask[SWR_BATCH][8];     // coverage masks
+    uint32_t wpre[SWR_BATCH][4];     // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
+    uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (pre[t] - 1) set for every pair t >= 1: pair of fragment g = #bits below g
+    uint32_t pre[SWR_BATCH + 4];     // exclusive prefix of covered counts
+    uint32_t touched[8];             // chunk duplicate election: pixels already claimed in this chunk
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -166,43 +194,39 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
     return base;
 }
 
-// SWR_RASTER_WPB waves (tiles) per workgroup: 1 lets the dispatcher backfill a finished tile's slot at once
-// (tile list lengths vary a lot), 4 shares one workgroup launch between a 2x2 tile quad.
-#ifndef SWR_RASTER_WPB
-#define SWR_RASTER_WPB 1
-#endif
 // PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
 // the switches fold away); -1 = read them from the draw at run time.
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
-__global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+__global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint16_t* __restrict__ counts) {
-    __shared__ WaveLdsC s_w[SWR_RASTER_WPB];
+    __shared__ WaveLdsC<PHONG> s_w;
     if (a.ctrl->poison) return;
 
-    const uint32_t nb = gridDim.x, b = blockIdx.x;
-    const uint32_t q = nb >> 3, r = nb & 7u, xcd = b & 7u, kk = b >> 3;
-    const uint32_t blk = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + kk;
-
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#if SWR_RASTER_WPB == 4
-    const int bx = (int)(blk % (uint32_t)a.blocks_x), by = (int)(blk / (uint32_t)a.blocks_x);
-    const int tx = bx * 2 + (wave & 1);
-    const int ty_local = by * 2 + (wave >> 1);
-#else
-    // one tile per workgroup; walk tiles in 2x2 quads so that neighbours (shared triangles) run close in time
-    const uint32_t quad = blk >> 2, sub = blk & 3u;
-    const int bx = (int)(quad % (uint32_t)a.blocks_x), by = (int)(quad / (uint32_t)a.blocks_x);
-    const int tx = bx * 2 + (int)(sub & 1u);
-    const int ty_local = by * 2 + (int)(sub >> 1);
-#endif
+    const int lane = threadIdx.x & 63;
+    const uint32_t tile_o = a.tile_order[blockIdx.x];                     // heaviest tiles first (k_tile_place)
+    const int tx = (int)(tile_o % (uint32_t)a.fp.tiles_x), ty_local = (int)(tile_o / (uint32_t)a.fp.tiles_x);
     const int ty = a.fp.band_ty0 + ty_local;
     if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
     const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
     const uint32_t n = a.tile_count[tile];
     if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
     const uint32_t start = a.tile_start[tile];
-    WaveLdsC& L = s_w[wave];
+    WaveLdsC<PHONG>& L = s_w;
+    auto load_varyings = [&L](int t) {
+        TriVaryings V;
+        V.a_clip = L.stage[4][t]; V.a_col = L.stage[5][t]; V.a_uvn = L.stage[6][t];
+        V.b_clip = L.stage[7][t]; V.b_col = L.stage[8][t]; V.b_uvn = L.stage[9][t];
+        V.c_clip = L.stage[10][t]; V.c_col = L.stage[11][t]; V.c_uvn = L.stage[12][t];
+        V.a_wnz = V.a_clip.x; V.b_wnz = V.b_clip.x; V.c_wnz = V.c_clip.x;
+        if (PHONG) {
+            const float4 a3 = L.stage[PHONG ? 13 : 0][t], b3 = L.stage[PHONG ? 14 : 0][t], c3 = L.stage[PHONG ? 15 : 0][t];
+            V.a_wpos[0] = a3.y; V.a_wpos[1] = a3.z; V.a_wpos[2] = a3.w;
+            V.b_wpos[0] = b3.y; V.b_wpos[1] = b3.z; V.b_wpos[2] = b3.w;
+            V.c_wpos[0] = c3.y; V.c_wpos[1] = c3.z; V.c_wpos[2] = c3.w;
+        }
+        return V;
+    };
 
     const int W = a.fp.width, H = a.fp.height;
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
@@ -222,97 +246,123 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
         else zz = inb ? a.depth[gi] : SWR_FLOAT_MINVALUE;
         L.col[p] = c;
         L.z[p] = zz;
-        L.owner[p] = 0xffffffffu;
     }
     unsigned n_tested = 0, n_shaded = 0, n_written = 0;
     uint32_t carry_key = 0xffffffffu;      // EARLYOUT: (pair, row) of the previous chunk's last fragment ...
     bool carry_dead = false;               // ... and whether that row segment has already hit its `break`
 #ifdef SWR_DEBUG_COUNTERS
-    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0;
+    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0;
 #endif
 
     for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
-        // ---- batch: the next (up to) 64 pairs of this tile; masks and counts staged in LDS ----
+        // ---- batch: the next (up to) SWR_BATCH pairs of this tile; empty pairs (binning is conservative) are dropped,
+        //      the rest is staged in LDS compacted ----
         const bool have = lane < SWR_BATCH && base + (uint32_t)lane < n;
         const uint32_t pidx = start + base + (uint32_t)lane;
         const uint32_t slot = have ? a.tile_list[pidx] : 0u;
         const int cnt = have ? (int)counts[pidx] : 0;
-        uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
-        if (cnt > 0) { m0 = masks[2 * (size_t)pidx]; m1 = masks[2 * (size_t)pidx + 1]; }
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         if (total == 0) continue;
-        if (lane < SWR_BATCH) {
-            *reinterpret_cast<uint4*>(&L.mask[lane][0]) = m0;
-            *reinterpret_cast<uint4*>(&L.mask[lane][4]) = m1;
-            L.slot[lane] = slot;
-            L.pre[lane] = (uint32_t)(cincl - cnt);
+        const unsigned long long nzb = __ballot(cnt > 0);
+        const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
+        if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        if (cnt > 0) {
+            const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
+            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + slot);
+            float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
+            const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f2.z));
+            const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f2.w));
+            const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f3.x));
+            const float4 a3 = pa[3], b3 = pb[3], c3 = pc[3];
+            float4 a0 = pa[0], b0 = pb[0], c0 = pc[0];
+            a0.x = a3.x; b0.x = b3.x; c0.x = c3.x;                           // clip.x is not read by fragments: wn.z rides there
+            L.stage[4][ci] = a0; L.stage[5][ci] = pa[1]; L.stage[6][ci] = pa[2];
+            L.stage[7][ci] = b0; L.stage[8][ci] = pb[1]; L.stage[9][ci] = pb[2];
+            L.stage[10][ci] = c0; L.stage[11][ci] = pc[1]; L.stage[12][ci] = pc[2];
+            if (PHONG) { L.stage[13][ci] = a3; L.stage[14][ci] = b3; L.stage[15][ci] = c3; }
+            {
+                const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
+                const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
+                const int fsX = max((int)(fbx & 0xffffu), x0), fsY = max((int)(fby & 0xffffu), y0);          // Rasterizer.cs:471-474
+                const uint32_t fs = (uint32_t)(fsX - x0) | ((uint32_t)(fsY - y0) << 8);
+                const float a01 = t0y - t1y, b01 = t1x - t0x;                                                 // :445-447
+                const float a12 = t1y - t2y, b12 = t2x - t1x;
+                const float a20 = t2y - t0y, b20 = t0x - t2x;
+                float4 r0;
+                if (LINES && (__float_as_uint(f3.w) & SWR_FLAG_LINE) != 0u) {
+                    r0 = make_float4(t0x, t1x, t0y, t1y);
+                } else {
+                    const float fsx = (float)fsX, fsy = (float)fsY;
+                    r0.x = a12 * (fsx - t1x) + b12 * (fsy - t1y);                                             // :481-483
+                    r0.y = a20 * (fsx - t2x) + b20 * (fsy - t2y);
+                    r0.z = a01 * (fsx - t0x) + b01 * (fsy - t0y);
+                    r0.w = f2.y;
+                }
+                L.stage[0][ci] = r0;
+                L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, f3.w);
+                L.stage[2][ci] = make_float4(a12, a20, a01, __uint_as_float(fs));
+                L.stage[3][ci] = make_float4(b12, b20, b01, 0.0f);
+            }
+            *reinterpret_cast<uint4*>(&L.mask[ci][0]) = m0;
+            *reinterpret_cast<uint4*>(&L.mask[ci][4]) = m1;
+            const uint32_t p1 = (uint32_t)__popc(m0.x), p2 = p1 + (uint32_t)__popc(m0.y), p3 = p2 + (uint32_t)__popc(m0.z),
+                           p4 = p3 + (uint32_t)__popc(m0.w), p5 = p4 + (uint32_t)__popc(m1.x), p6 = p5 + (uint32_t)__popc(m1.y),
+                           p7 = p6 + (uint32_t)__popc(m1.z);
+            *reinterpret_cast<uint4*>(&L.wpre[ci][0]) = make_uint4(p1 << 16, p2 | (p3 << 16), p4 | (p5 << 16), p6 | (p7 << 16));
+            const uint32_t pre = (uint32_t)(cincl - cnt);
+            L.pre[ci] = pre;
+            if (ci > 0) atomicOr(&L.head[(pre - 1u) >> 5], 1u << ((pre - 1u) & 31u));
         }
-        if (lane == 0) L.pre[SWR_BATCH] = (uint32_t)total;
         n_tested += (unsigned)cnt;
 #ifdef SWR_DEBUG_COUNTERS
         ++dbg_batches;
 #endif
 
         // ---- fragment stream of the batch, 64 at a time ----
+        int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
-            // pair of fragment g: largest t with pre[t] <= g  (pre is non-decreasing, pre[0] = 0)
-            int lo = 0, hi = SWR_BATCH;
-#pragma unroll
-            for (int it = 0; it < (SWR_BATCH == 64 ? 6 : 5); ++it) {
-                const int mid = (lo + hi) >> 1;
-                const bool le = (int)L.pre[mid] <= g;
-                lo = le ? mid : lo;
-                hi = le ? hi : mid;
-            }
-#ifdef SWR_ABLATE_SEARCH
-            const int t = (lane >> 4) & 3; asm volatile("" :: "v"(lo));
-#else
-            const int t = lo;
-#endif
+            // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
+            const int hw = pos >> 5, hs = pos & 31;
+            const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
+            const uint32_t win_lo = __builtin_amdgcn_alignbit(h1, h0, hs), win_hi = __builtin_amdgcn_alignbit(h2, h1, hs);
+            const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
             int k = valid ? g - (int)L.pre[t] : 0;
-            const uint32_t fslot = L.slot[t];
-            const TriRec* __restrict__ rp = a.recs + fslot;
-            const float4* __restrict__ fq = reinterpret_cast<const float4*>(rp);
-            const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
-            // k-th covered pixel of pair t in row-major order
-            const uint4 ma = *reinterpret_cast<const uint4*>(&L.mask[t][0]);
-            const uint4 mb = *reinterpret_cast<const uint4*>(&L.mask[t][4]);
-            int pix = 0;
+            const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
+            // k-th covered pixel of pair t in row-major order: the mask word by a 16-bit-field compare against the
+            // word prefix counts, then a 5-level selection inside the word
+            int pix;
             {
-                // k-th set bit of the 256-bit mask: 3-level selection over the 8 words, then inside the word
-                const int c0 = __popc(ma.x), c1 = __popc(ma.y), c2 = __popc(ma.z), c3 = __popc(ma.w);
-                const int c4 = __popc(mb.x), c5 = __popc(mb.y), c6 = __popc(mb.z);
-                const int s01 = c0 + c1, s23 = c2 + c3, s45 = c4 + c5, s0123 = s01 + s23;
-                const bool up1 = k >= s0123;
-                k -= up1 ? s0123 : 0;
-                const uint32_t a0 = up1 ? mb.x : ma.x, a1 = up1 ? mb.y : ma.y, a2 = up1 ? mb.z : ma.z, a3 = up1 ? mb.w : ma.w;
-                const int sa = up1 ? s45 : s01, ca0 = up1 ? c4 : c0, ca2 = up1 ? c6 : c2;
-                const bool up2 = k >= sa;
-                k -= up2 ? sa : 0;
-                const uint32_t b0 = up2 ? a2 : a0, b1 = up2 ? a3 : a1;
-                const int cb0 = up2 ? ca2 : ca0;
-                const bool up3 = k >= cb0;
-                k -= up3 ? cb0 : 0;
-                const uint32_t wsel = up3 ? b1 : b0;
-                const int wi = (up1 ? 4 : 0) + (up2 ? 2 : 0) + (up3 ? 1 : 0);
-                const bool okk = valid && k < __popc(wsel);          // always true for a valid fragment
-                pix = wi * 32 + kth_set_bit32(wsel, okk ? k : 0);
+                const uint4 wp = *reinterpret_cast<const uint4*>(&L.wpre[t][0]);
+                const uint32_t kk = ((uint32_t)k | ((uint32_t)k << 16)) | 0x80008000u;
+                const int nle = __popc((kk - wp.x) & 0x80008000u) + __popc((kk - wp.y) & 0x80008000u) +
+                                __popc((kk - wp.z) & 0x80008000u) + __popc((kk - wp.w) & 0x80008000u);    // fields <= k, >= 1
+                const int wi = nle - 1;
+                const uint32_t wsel = L.mask[t][wi];
+                const int kw = k - (int)reinterpret_cast<const uint16_t*>(&L.wpre[t][0])[wi];
+                const bool okk = valid && kw < __popc(wsel);         // always true for a valid fragment
+                pix = wi * 32 + kth_set_bit32(wsel, okk ? kw : 0);
             }
-#ifdef SWR_ABLATE_KTH
-            asm volatile("" :: "v"(pix)); pix = (g * 7) & 255;
-#endif
-            // duplicate election: the lowest lane touching a pixel owns it; any other lane on that pixel must wait
-            if (valid) atomicMin(&L.owner[pix], (uint32_t)lane);
-            const uint32_t dflags = __float_as_uint(f3.w);
+            // duplicate election: a lane whose pixel was already claimed in this chunk must wait.  Which of two lanes
+            // sharing a pixel loses does not matter: the chunk is cut at the LOWEST loser, so no two lanes before the
+            // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
+            const int pix_first = __builtin_amdgcn_readfirstlane(pix);
+            if (lane < 8) L.touched[lane] = (lane == (pix_first >> 5)) ? (1u << (pix_first & 31)) : 0u;
+            const uint32_t pbit = 1u << (pix & 31);
+            bool dup = false;
+            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix >> 5], pbit) & pbit) != 0u;
+            const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
-            const bool dup = valid && L.owner[pix] != (uint32_t)lane;
             const unsigned long long stop = __ballot(!valid || dup || draw != draw0);
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
-            if (valid) L.owner[pix] = 0xffffffffu;
+            {
+                const unsigned long long win = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)win_hi) << 32) |
+                                               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)win_lo);
+                t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
+            }
             const bool act = lane < cut;
 #ifdef SWR_DEBUG_COUNTERS
             ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
@@ -320,43 +370,49 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
+#ifdef SWR_DEBUG_COUNTERS
+            int dbg_nrow = 0, dbg_ncol = 0;
+#endif
             bool e_pass = false, e_alpha = false;          // EARLYOUT: results held until the row kills are known
             float e_d = 0.0f;
             float4 e_src = make_float4(0.f, 0.f, 0.f, 0.f);
             if (act) {
-                const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
-                const float d0 = f1.z, d1 = f1.w, d2 = f2.x, inv_area = f2.y;
-                const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
-                const int fsX = max((int)(fbx & 0xffffu), x0), fsY = max((int)(fby & 0xffffu), y0);
-                const int px = x0 + (pix & 15), py = y0 + (pix >> 4);
+                const float d0 = f1.x, d1 = f1.y, d2 = f1.z;
+                const uint32_t fs = __float_as_uint(f2.w);
                 const bool is_line = LINES && (dflags & SWR_FLAG_LINE) != 0u;
                 float w0f, w1f, w2f, d;
                 if (is_line) {
                     // DrawLine fragment, Rasterizer.cs:299-322: weights (1-t, t, 0) on outputs[0], outputs[1], outputs[0]
                     float t;
-                    (void)line_test(t0x, t0y, t1x, t1y, px, py, t);
+                    (void)line_test(f0.x, f0.z, f0.y, f0.w, x0 + (pix & 15), y0 + (pix >> 4), t);
                     w0f = 1.0f - t; w1f = t; w2f = 0.0f;
                     d = 1.0f / (d0 * (1.0f - t) + d1 * t);                                                // :315
                 } else {
-                    const float a01 = t0y - t1y, b01 = t1x - t0x;
-                    const float a12 = t1y - t2y, b12 = t2x - t1x;
-                    const float a20 = t2y - t0y, b20 = t0x - t2x;
-                    const float fsx = (float)fsX, fsy = (float)fsY;
-                    float w0 = a12 * (fsx - t1x) + b12 * (fsy - t1y);                                     // :481-483
-                    float w1 = a20 * (fsx - t2x) + b20 * (fsy - t2y);
-                    float w2 = a01 * (fsx - t0x) + b01 * (fsy - t0y);
-                    const int nrow = py - fsY, ncol = px - fsX;
-                    for (int i = 0; i < nrow; ++i) { w0 += b12; w1 += b20; w2 += b01; }                   // :532-534
-                    for (int i = 0; i < ncol; ++i) { w0 += a12; w1 += a20; w2 += a01; }                   // :527-529
+                    // replay of the reference's add chain from the pair's first pixel: rows first, then columns
+                    float w0 = f0.x, w1 = f0.y, w2 = f0.z;
+                    const float inv_area = f0.w;
+#ifdef SWR_ABL_NOREPLAY
+                    const int nrow = 0, ncol = 0; asm volatile("" :: "v"(fs));
+#else
+                    const int nrow = (pix >> 4) - (int)(fs >> 8), ncol = (pix & 15) - (int)(fs & 0xffu);
+#endif
+#ifdef SWR_DEBUG_COUNTERS
+                    dbg_nrow = nrow; dbg_ncol = ncol;
+#endif
+                    for (int i = 0; i < nrow; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }                // :532-534
+                    for (int i = 0; i < ncol; ++i) { w0 += f2.x; w1 += f2.y; w2 += f2.z; }                // :527-529
                     w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }
                 if (!EARLYOUT) {
                     if (depth_func(f_dt, d, L.z[pix])) {                                                   // :505 / :318
                         ++n_shaded;
-                        const float4 src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
-                                                                a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
-                                                                a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);     // :507-509 / :321-323
+#ifdef SWR_ABL_NOSHADE
+                        const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
+#else
+                        const float4 src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                                                                 load_varyings(t), w0f, w1f, w2f);   // :507-509 / :321-323
+#endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
                         if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
                             const float4 dst = L.col[pix];
@@ -369,13 +425,20 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
                     e_d = d;
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
-                        e_src = shade_fragment<true, PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
-                                                            a.vout + __float_as_uint(f2.z), a.vout + __float_as_uint(f2.w),
-                                                            a.vout + __float_as_uint(f3.x), w0f, w1f, w2f);
+                        e_src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                                                      load_varyings(t), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }
                 }
             }
+#ifdef SWR_DEBUG_COUNTERS
+            {
+                int mr = act ? dbg_nrow : 0, mc = act ? dbg_ncol : 0, sr = mr, sc = mc;
+                for (int off = 32; off > 0; off >>= 1) { mr = max(mr, __shfl_xor(mr, off)); mc = max(mc, __shfl_xor(mc, off));
+                                                         sr += __shfl_xor(sr, off); sc += __shfl_xor(sc, off); }
+                dbg_chain += (unsigned)mr; dbg_chain_c += (unsigned)mc; dbg_sum_r += (unsigned)sr; dbg_sum_c += (unsigned)sc;
+            }
+#endif
             if (EARLYOUT) {
                 // canEarlyOut (Rasterizer.cs:430,520-523): under BlendMode.None the first fragment of a row (within this
                 // triangle and tile) that passes depth but fails alpha ends the row -- nothing to its right is visited.
@@ -445,6 +508,8 @@ __global__ __launch_bounds__(64 * SWR_RASTER_WPB, SWR_RASTER_MINWAVES) void k_ra
     if (lane == 0 && a.dbg) {
         atomicAdd(&a.dbg[0], (unsigned long long)dbg_batches); atomicAdd(&a.dbg[1], (unsigned long long)dbg_chunks);
         atomicAdd(&a.dbg[4], (unsigned long long)dbg_chunk_lanes); atomicAdd(&a.dbg[3], (unsigned long long)dbg_chain);
+        atomicAdd(&a.dbg[2], (unsigned long long)dbg_chain_c); atomicAdd(&a.dbg[5], (unsigned long long)dbg_sum_r);
+        atomicAdd(&a.dbg[6], (unsigned long long)dbg_sum_c);
     }
 #endif
 }
