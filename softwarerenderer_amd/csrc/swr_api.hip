@@ -105,7 +105,7 @@ struct swr_context {
     DevBuf d_upload, d_vout, d_recs, d_slot_tb;   // d_upload = draws | vertex block map | triangle block map of the running batch
     FrameSlot slots[SWR_SLOTS];
     uint32_t slot_next = 0;
-    DevBuf d_pair_tile, d_masks, d_pcounts, d_ctrl;
+    DevBuf d_pair_tile, d_masks, d_pcounts, d_pair_refs, d_ctrl;
     uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32: heaviest-first raster order
@@ -270,13 +270,15 @@ enum { MODE_SYNC = 0, MODE_ASYNC = 1 };
 const unsigned long long kMaxPairs = 1ull << 30;       // list entries per round (4 GiB of slot ids)
 
 size_t pair_capacity(const swr_context* c) {
-    return std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 2));
+    return std::min(std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 2)),
+                    c->d_pair_refs.cap / 16);
 }
 int ensure_pairs(swr_context* c, size_t n) {
     int rc;
     if ((rc = ensure(c, c->d_tile_list, n * 4))) return rc;
     if ((rc = ensure(c, c->d_pair_tile, n * 4))) return rc;
     if ((rc = ensure(c, c->d_masks, n * 32))) return rc;
+    if ((rc = ensure(c, c->d_pair_refs, n * 16))) return rc;
     return ensure(c, c->d_pcounts, n * 2 + 64);
 }
 
@@ -296,15 +298,8 @@ int run_clear(swr_context* c, bool& cc, bool& cd, const float rgba_[4]) {
 
 // bins slots [lo, hi) and rasterises them.  MODE_SYNC reads the pair total back (sizes buffers exactly, splits a
 // range that would need more than kMaxPairs entries); MODE_ASYNC launches everything against the current capacity.
-int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode) {
-    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
-    if (n_tiles == 0 || lo >= hi) return SWR_OK;
-    int rc;
-    const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
-    unsigned long long* d_total = c->d_total.as<unsigned long long>();
-    uint32_t* tile_work = c->d_order.as<uint32_t>();
-    uint32_t* tile_order = tile_work + n_tiles;
-    uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
+// the BinArgs of one round (slots [lo, hi) of batch b)
+static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32_t hi) {
     BinArgs ba;
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
     ba.recs = c->d_recs.as<TriRec>();
@@ -317,8 +312,21 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     ba.tile_list = c->d_tile_list.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
-    ba.ctrl = ctrl;
-    ba.total = d_total;
+    ba.ctrl = c->d_ctrl.as<Ctrl>();
+    ba.total = c->d_total.as<unsigned long long>();
+    return ba;
+}
+
+int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode) {
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+    if (n_tiles == 0 || lo >= hi) return SWR_OK;
+    int rc;
+    const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
+    unsigned long long* d_total = c->d_total.as<unsigned long long>();
+    uint32_t* tile_work = c->d_order.as<uint32_t>();
+    uint32_t* tile_order = tile_work + n_tiles;
+    uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
+    BinArgs ba = make_bin_args(c, b, lo, hi);
     const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;
     const uint32_t bin_blocks = (bin_threads + 255u) / 256u;
     {
@@ -379,6 +387,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.pair_tile = c->d_pair_tile.as<uint32_t>();
         ca.masks = c->d_masks.as<uint4>();
         ca.counts = c->d_pcounts.as<uint16_t>();
+        ca.refs = c->d_pair_refs.as<uint4>();
         ca.n_pairs = d_total;
         ca.tile_work = tile_work;
         ca.ctrl = ctrl;
@@ -408,7 +417,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
         ra.tile_start = c->d_tile_start.as<uint32_t>();
         ra.tile_count = c->d_tile_count.as<uint32_t>();
-        ra.tile_list = c->d_tile_list.as<uint32_t>();
+        ra.pair_refs = c->d_pair_refs.as<uint4>();
         ra.color = c->color; ra.depth = c->depth;
         ra.tile_stats = c->d_tile_stats.as<uint32_t>();
         memcpy(ra.clear_rgba, b.clear_rgba, 16);
@@ -724,7 +733,7 @@ void swr_destroy(swr_context* c) {
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
     if (c->host_poison) (void)hipHostFree(c->host_poison);
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
-                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
+                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -79,144 +79,151 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
     return !(any_neg && any_pos);
 }
 
-// Adds (tile, slot) pairs for the lanes with want == true.  Lanes of a wave usually hold neighbouring triangles
-// of one mesh, i.e. few distinct tiles: one atomic per DISTINCT tile per call (leader election by ballot),
-// ranks inside the group by mbcnt.  The order inside a tile's list is irrelevant here (k_sort_tiles fixes it).
-// Adds (tile, slot) pairs for the lanes with want == true.  Lanes of a wave usually hold neighbouring triangles
-// of one mesh, i.e. few distinct tiles: one atomic per DISTINCT tile per call (leader election by ballot),
-// ranks inside the group by mbcnt.  The order inside a tile's list is irrelevant here (k_sort_tiles fixes it).
-// Split in two so that a caller can issue the atomics of ALL its steps before consuming any returned base
-// (each consumption costs an atomic round trip).
-struct BinTicket { int leader; uint32_t rank; uint32_t base_reg; };
+// what binning needs to know about one primitive slot
+struct SlotData {
+    int tminx, tminy, nx, ny;            // tile bbox clamped to the band (nx = ny = 0: nothing to bin)
+    float sx[3], sy[3];
+    int minX, maxX, minY, maxY;          // pixel bbox
+    bool is_line;
+};
+__device__ __forceinline__ SlotData slot_none() {
+    SlotData s;
+    s.tminx = s.tminy = s.nx = s.ny = 0;
+    s.sx[0] = s.sx[1] = s.sx[2] = s.sy[0] = s.sy[1] = s.sy[2] = 0.f;
+    s.minX = s.minY = 0; s.maxX = s.maxY = -1; s.is_line = false;
+    return s;
+}
+// tile bbox word (k_setup) -> clamped to the band; false when the slot has nothing in this band
+__device__ __forceinline__ bool slot_tiles(const BinArgs& a, unsigned long long tb, SlotData& s) {
+    if (tb == SWR_TB_INVALID) return false;
+    s.tminx = (int)(tb & 0xffff);
+    const int tmaxx = (int)((tb >> 16) & 0xffff);
+    s.tminy = max((int)((tb >> 32) & 0xffff), a.band_ty0);
+    const int tmaxy = min((int)((tb >> 48) & 0xffff), a.band_ty1 - 1);
+    s.nx = tmaxx - s.tminx + 1;
+    s.ny = tmaxy - s.tminy + 1;
+    if (s.ny <= 0) { s.nx = 0; s.ny = 0; return false; }
+    return true;
+}
+__device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot) {
+    SlotData s = slot_none();
+    if (slot < a.slot_hi && slot_tiles(a, a.slot_tb[slot], s)) {
+        const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
+        const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
+        s.sx[0] = r0.x; s.sx[1] = r0.y; s.sx[2] = r0.z; s.sy[0] = r0.w; s.sy[1] = r1.x; s.sy[2] = r1.y;
+        const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
+        s.minX = (int)(bbx & 0xffffu); s.maxX = (int)(bbx >> 16); s.minY = (int)(bby & 0xffffu); s.maxY = (int)(bby >> 16);
+        s.is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+    }
+    return s;
+}
 
+// Triangles spanning more than 8 tiles: spread over the wave one at a time (every lane must call).
 template <bool FILL>
-__device__ __forceinline__ BinTicket bin_issue(const BinArgs& a, bool want, uint32_t tile) {
-    const int lane = (int)(threadIdx.x & 63u);
-    unsigned long long todo = __ballot(want);
-    BinTicket t; t.leader = lane; t.rank = 0; t.base_reg = 0;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t t0 = (uint32_t)__shfl((int)tile, leader);
-        const bool in_group = want && tile == t0;
-        const unsigned long long same = __ballot(in_group);
-        if (in_group) {
-            t.leader = leader;
-            t.rank = __builtin_amdgcn_mbcnt_hi((unsigned)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)same, 0u));
+__device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, uint32_t slot, bool big) {
+    const int lane = threadIdx.x & 63;
+    const int nt = sd.nx * sd.ny;
+    unsigned long long m = __ballot(big);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int s_tminx = __shfl(sd.tminx, src), s_tminy = __shfl(sd.tminy, src);
+        const int s_nx = __shfl(sd.nx, src), s_nt = __shfl(nt, src);
+        const uint32_t s_slot = (uint32_t)__shfl((int)slot, src);
+        float bsx[3], bsy[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sd.sx[k], src); bsy[k] = __shfl(sd.sy[k], src); }
+        const int bminX = __shfl(sd.minX, src), bmaxX = __shfl(sd.maxX, src), bminY = __shfl(sd.minY, src), bmaxY = __shfl(sd.maxY, src);
+        const bool b_line = __shfl((int)sd.is_line, src) != 0;
+        for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
+            const int i = i0 + lane;
+            bool want = i < s_nt;
+            int ty = 0, tx = 0;
+            if (want) {
+                ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
+                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
+            }
+            if (want) {
+                const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                if (FILL) {
+                    const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
+                    if (at < a.list_capacity) a.tile_list[at] = s_slot;
+                    else a.counters->overflow = 1u;
+                } else {
+                    atomicAdd(&a.tile_count[tile], 1u);
+                }
+            }
         }
-        if (lane == leader) {
-            if (FILL) t.base_reg = atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
-            else atomicAdd(&a.tile_count[t0], (uint32_t)__popcll(same));
-        }
-        todo &= ~same;
-    }
-    return t;
-}
-__device__ __forceinline__ void bin_commit(const BinArgs& a, const BinTicket& t, bool want, uint32_t tile, uint32_t slot) {
-    const uint32_t base = (uint32_t)__shfl((int)t.base_reg, t.leader);
-    if (want) {
-        const uint32_t at = a.tile_start[tile] + base + t.rank;
-        if (at < a.list_capacity) a.tile_list[at] = slot;
-        else a.counters->overflow = 1u;
     }
 }
 
-// thread per slot; triangles spanning many tiles are spread over the whole wave
+// Thread per submitted triangle, walking its `spt` slots (the odd fan slots are almost always empty).
+// Triangles of <= 8 tiles (nearly all): the block's (tile, slot) pairs are first combined in an LDS hash table
+// keyed by tile -- neighbouring triangles share tiles, so 256 triangles touch few distinct ones -- and only one
+// global atomic per distinct tile leaves the block; FILL gets each pair's rank from the LDS add and the tile's base
+// from that one global atomic.  The order inside a tile's list is irrelevant here (k_sort_tiles restores it).
+#define SWR_BIN_TABLE 4096          // >= 2 x (256 threads x 8 tiles): open addressing always terminates
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
+    __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
+    __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && a.ctrl->poison) return;
-    const int lane = threadIdx.x & 63;
     const uint32_t first = a.slot_lo + (blockIdx.x * 256u + threadIdx.x) * a.spt;
     for (uint32_t si = 0; si < a.spt; ++si) {
         const uint32_t slot = first + si;
-        int tminx = 0, tminy = 0, nx = 0, ny = 0;
-        float sx[3] = { 0.f, 0.f, 0.f }, sy[3] = { 0.f, 0.f, 0.f };
-        int minX = 0, maxX = -1, minY = 0, maxY = -1;
-        bool is_line = false;
-        if (slot < a.slot_hi) {
-            unsigned long long tb = a.slot_tb[slot];
-            if (tb != SWR_TB_INVALID) {
-                tminx = (int)(tb & 0xffff);
-                int tmaxx = (int)((tb >> 16) & 0xffff);
-                tminy = (int)((tb >> 32) & 0xffff);
-                int tmaxy = (int)((tb >> 48) & 0xffff);
-                tminy = max(tminy, a.band_ty0);
-                tmaxy = min(tmaxy, a.band_ty1 - 1);
-                nx = tmaxx - tminx + 1;
-                ny = tmaxy - tminy + 1;
-                if (ny <= 0) { nx = 0; ny = 0; }
-                else {
-                    const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
-                    const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
-                    sx[0] = r0.x; sx[1] = r0.y; sx[2] = r0.z; sy[0] = r0.w; sy[1] = r1.x; sy[2] = r1.y;
-                    const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
-                    minX = (int)(bbx & 0xffffu); maxX = (int)(bbx >> 16); minY = (int)(bby & 0xffffu); maxY = (int)(bby >> 16);
-                    is_line = (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
-                }
-            }
-        }
-        const int nt = nx * ny;
+        const SlotData sd = slot_load(a, slot);
+        const int nt = sd.nx * sd.ny;
         const bool big = nt > 8;
-        {
-            // small triangles (<= 8 tiles of bbox): step i handles every lane's i-th tile; all atomics first, then the stores
-            const int nt_small = big ? 0 : nt;
-            int nt_max = nt_small;
-    #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) nt_max = max(nt_max, __shfl_xor(nt_max, off));
-            bool want[8];
-            uint32_t tile[8];
-            BinTicket tk[8];
-            int wtx = tminx, wty = tminy;                 // row-major walk of the tile bbox without integer division
-    #pragma unroll
+        const int nt_small = big ? 0 : nt;
+        if (!__syncthreads_or(nt != 0)) continue;                  // block-uniform (also orders the table's reuse)
+        for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) { s_key[e] = 0u; s_val[e] = 0u; }
+        __syncthreads();
+        // phase 1: every wanted (tile, slot) pair into the table; packed[i] = entry | rank << 12 | wanted << 31
+        uint32_t packed[8];
+        int wtx = sd.tminx, wty = sd.tminy;                         // row-major walk of the tile bbox without integer division
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            packed[i] = 0u;
+            if (i < nt_small) {
+                const bool want = pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
+                if (want) {
+                    const uint32_t tile = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
+                    uint32_t e = (tile * 0x9E3779B1u) >> 20;        // 12 bits
+                    for (;;) {
+                        const uint32_t prev = atomicCAS(&s_key[e], 0u, tile + 1u);
+                        if (prev == 0u || prev == tile + 1u) break;
+                        e = (e + 1u) & (SWR_BIN_TABLE - 1u);
+                    }
+                    const uint32_t rank = atomicAdd(&s_val[e], 1u);       // < 2048
+                    packed[i] = e | (rank << 12) | 0x80000000u;
+                }
+                ++wtx;
+                if (wtx >= sd.tminx + sd.nx) { wtx = sd.tminx; ++wty; }
+            }
+        }
+        __syncthreads();
+        // phase 2: one global atomic per distinct tile of the block
+        for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) {
+            const uint32_t key = s_key[e];
+            if (key) {
+                const uint32_t tile = key - 1u, n = s_val[e];
+                if (FILL) s_val[e] = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], n);
+                else atomicAdd(&a.tile_count[tile], n);
+            }
+        }
+        if (FILL) {
+            __syncthreads();
+            // phase 3: list position = the tile's base for this block + the pair's rank in the block
+#pragma unroll
             for (int i = 0; i < 8; ++i) {
-                want[i] = false; tile[i] = 0;
-                if (i < nt_max) {
-                    if (i < nt_small) {
-                        want[i] = pair_may_cover(sx, sy, minX, maxX, minY, maxY, wtx, wty, a.width, a.height, is_line);
-                        tile[i] = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
-                        ++wtx;
-                        if (wtx >= tminx + nx) { wtx = tminx; ++wty; }
-                    }
-                    tk[i] = bin_issue<FILL>(a, want[i], tile[i]);
-                }
-            }
-            if (FILL) {
-    #pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    if (i < nt_max) bin_commit(a, tk[i], want[i], tile[i], slot);
-            }
-        }
-        unsigned long long m = __ballot(big);
-        while (m) {
-            const int src = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const int s_tminx = __shfl(tminx, src), s_tminy = __shfl(tminy, src);
-            const int s_nx = __shfl(nx, src), s_nt = __shfl(nt, src);
-            const uint32_t s_slot = (uint32_t)__shfl((int)slot, src);
-            float bsx[3], bsy[3];
-    #pragma unroll
-            for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sx[k], src); bsy[k] = __shfl(sy[k], src); }
-            const int bminX = __shfl(minX, src), bmaxX = __shfl(maxX, src), bminY = __shfl(minY, src), bmaxY = __shfl(maxY, src);
-            const bool b_line = __shfl((int)is_line, src) != 0;
-            for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
-                const int i = i0 + lane;
-                bool want = i < s_nt;
-                int ty = 0, tx = 0;
-                if (want) {
-                    ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
-                    want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
-                }
-                if (want) {
-                    const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
-                    if (FILL) {
-                        const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
-                        if (at < a.list_capacity) a.tile_list[at] = s_slot;
-                        else a.counters->overflow = 1u;
-                    } else {
-                        atomicAdd(&a.tile_count[tile], 1u);
-                    }
+                if (packed[i] & 0x80000000u) {
+                    const uint32_t at = s_val[packed[i] & 0xfffu] + ((packed[i] >> 12) & 0x7ffffu);
+                    if (at < a.list_capacity) a.tile_list[at] = slot;
+                    else a.counters->overflow = 1u;
                 }
             }
         }
+        bin_big<FILL>(a, sd, slot, big);
     }
 }
 

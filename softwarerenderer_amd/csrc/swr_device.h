@@ -21,6 +21,8 @@
 #define SWR_FLAG_LINE   0x40000000u      // record is one DrawLine edge of DebugMode.Wireframe: sx/sy[0..1] = p0, p1
 #define SWR_DRAW_MASK   0x3fffffffu
 
+#define SWR_TB_INVALID 0xffffffffffffffffull     // slot_tb word of a slot with nothing to rasterise
+
 namespace swr {
 
 // ---------------------------------------------------------------- device records ----

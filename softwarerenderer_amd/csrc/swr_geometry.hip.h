@@ -84,8 +84,6 @@ __device__ __forceinline__ void load_vout(const VOut* __restrict__ src, VOut& v)
     v.wn[2] = d.x; v.wpos[0] = d.y; v.wpos[1] = d.z; v.wpos[2] = d.w;
 }
 
-#define SWR_TB_INVALID 0xffffffffffffffffull
-
 // DrawTriangle + RasterizeTriangle prologue for one (possibly clipped) triangle.
 // v0,v1,v2 in submission order; r0,r1,r2 their VOut indices.  Fills rec[0] / tb[0] and returns 1 when the
 // triangle reaches the tile loop.  In DebugMode.Wireframe (Rasterizer.cs:419-425) it emits instead up to three

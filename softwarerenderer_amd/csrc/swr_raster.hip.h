@@ -17,7 +17,7 @@ struct RasterArgs {
     const DrawParams* __restrict__ draws;
     const uint32_t* __restrict__ tile_start;
     const uint32_t* __restrict__ tile_count;
-    const uint32_t* __restrict__ tile_list;
+    const uint4* __restrict__ pair_refs;       // per pair {slot, vertex refs of outputs[0..2]} (k_cover)
     const uint32_t* __restrict__ tile_order;   // band-local tile index per workgroup
     float4* __restrict__ color;
     float* __restrict__ depth;

@@ -35,6 +35,8 @@ struct CoverArgs {
     const uint32_t* __restrict__ pair_tile;   // band-local tile index per pair
     uint4* __restrict__ masks;                // 2 x uint4 per pair: row r -> bits (r & 1) * 16 .. of word r >> 1
     uint16_t* __restrict__ counts;            // popcount of the mask
+    uint4* __restrict__ refs;                 // {slot, vertex references of outputs[0..2]}: the raster kernel's batch set-up
+                                              // then needs no load that depends on another load
     const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
     uint32_t* __restrict__ tile_work;         // per tile: sum of the counts (raster scheduling weight)
     const Ctrl* __restrict__ ctrl;
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
-        const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
+        const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+        a.refs[p] = make_uint4(slot, __float_as_uint(r2.z), __float_as_uint(r2.w), __float_as_uint(r3.x));
         const float s0x = r0.x, s1x = r0.y, s2x = r0.z, s0y = r0.w, s1y = r1.x, s2y = r1.y;
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
@@ -231,6 +234,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     const int W = a.fp.width, H = a.fp.height;
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
 
+    // pair references and counts are fetched one batch ahead, so a batch set-up is ONE memory round trip
+    // (masks, TriRec and the three outputs are then independent loads)
+    uint4 ref_next = make_uint4(0u, 0u, 0u, 0u);
+    int cnt_next = 0;
+    if (lane < SWR_BATCH && (uint32_t)lane < n) { ref_next = a.pair_refs[start + (uint32_t)lane]; cnt_next = (int)counts[start + (uint32_t)lane]; }
+
     // ---- tile init: clear fused, or one coalesced read of the framebuffer ----
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -257,10 +266,14 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
         // ---- batch: the next (up to) SWR_BATCH pairs of this tile; empty pairs (binning is conservative) are dropped,
         //      the rest is staged in LDS compacted ----
-        const bool have = lane < SWR_BATCH && base + (uint32_t)lane < n;
         const uint32_t pidx = start + base + (uint32_t)lane;
-        const uint32_t slot = have ? a.tile_list[pidx] : 0u;
-        const int cnt = have ? (int)counts[pidx] : 0;
+        const uint4 ref = ref_next;
+        const int cnt = cnt_next;
+        {
+            const uint32_t nb = base + (uint32_t)SWR_BATCH + (uint32_t)lane;
+            ref_next = make_uint4(0u, 0u, 0u, 0u); cnt_next = 0;
+            if (lane < SWR_BATCH && nb < n) { ref_next = a.pair_refs[start + nb]; cnt_next = (int)counts[start + nb]; }
+        }
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         if (total == 0) continue;
@@ -269,18 +282,18 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
             const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
-            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + slot);
-            float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
-            const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f2.z));
-            const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f2.w));
-            const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + __float_as_uint(f3.x));
+            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
+            const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
+            const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
+            const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + ref.z);
+            const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + ref.w);
             const float4 a3 = pa[3], b3 = pb[3], c3 = pc[3];
             float4 a0 = pa[0], b0 = pb[0], c0 = pc[0];
             a0.x = a3.x; b0.x = b3.x; c0.x = c3.x;                           // clip.x is not read by fragments: wn.z rides there
             L.stage[4][ci] = a0; L.stage[5][ci] = pa[1]; L.stage[6][ci] = pa[2];
             L.stage[7][ci] = b0; L.stage[8][ci] = pb[1]; L.stage[9][ci] = pb[2];
             L.stage[10][ci] = c0; L.stage[11][ci] = pc[1]; L.stage[12][ci] = pc[2];
-            if (PHONG) { L.stage[13][ci] = a3; L.stage[14][ci] = b3; L.stage[15][ci] = c3; }
+            if (PHONG) { L.stage[PHONG ? 13 : 0][ci] = a3; L.stage[PHONG ? 14 : 0][ci] = b3; L.stage[PHONG ? 15 : 0][ci] = c3; }
             {
                 const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
                 const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
@@ -502,7 +515,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     }
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;
-        ts[0] += n_tested; ts[1] += n_shaded; ts[2] += n_written;
+        atomicAdd(&ts[0], n_tested); atomicAdd(&ts[1], n_shaded); atomicAdd(&ts[2], n_written);     // no return value: no round trip
     }
 #ifdef SWR_DEBUG_COUNTERS
     if (lane == 0 && a.dbg) {
