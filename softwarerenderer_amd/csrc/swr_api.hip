@@ -108,6 +108,7 @@ struct swr_context {
     DevBuf d_pair_tile, d_masks, d_pcounts, d_pair_refs, d_ctrl;
     uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
+    DevBuf d_want;           // 1 byte per slot: COUNT's pair_may_cover decisions, replayed by FILL
     DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32: heaviest-first raster order
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
@@ -314,6 +315,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     ba.counters = c->d_counters.as<Counters>();
     ba.ctrl = c->d_ctrl.as<Ctrl>();
     ba.total = c->d_total.as<unsigned long long>();
+    ba.want = c->d_want.as<uint8_t>();
     return ba;
 }
 
@@ -485,6 +487,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
     if ((rc = ensure(c, c->d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
     if ((rc = ensure(c, c->d_slot_tb, (size_t)(spt * T) * 8))) return rc;
+    if ((rc = ensure(c, c->d_want, (size_t)(spt * T) + 64))) return rc;
     if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 8 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
@@ -733,7 +736,7 @@ void swr_destroy(swr_context* c) {
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
     if (c->host_poison) (void)hipHostFree(c->host_poison);
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
-                       &c->d_slot_tb, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
+                       &c->d_slot_tb, &c->d_want, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -31,6 +31,7 @@ struct BinArgs {
     Counters* __restrict__ counters;
     const Ctrl* __restrict__ ctrl;
     const unsigned long long* __restrict__ total;
+    uint8_t* __restrict__ want;          // per slot: which of its (<= 8) tiles passed pair_may_cover -- written by COUNT, read by FILL
 };
 
 // Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
@@ -105,9 +106,10 @@ __device__ __forceinline__ bool slot_tiles(const BinArgs& a, unsigned long long 
     if (s.ny <= 0) { s.nx = 0; s.ny = 0; return false; }
     return true;
 }
-__device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot) {
+// with_rec = false: only the tile bbox (FILL of a small triangle replays COUNT's decisions from a.want)
+__device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot, bool with_rec_small) {
     SlotData s = slot_none();
-    if (slot < a.slot_hi && slot_tiles(a, a.slot_tb[slot], s)) {
+    if (slot < a.slot_hi && slot_tiles(a, a.slot_tb[slot], s) && (with_rec_small || s.nx * s.ny > 8)) {
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
         const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
         s.sx[0] = r0.x; s.sx[1] = r0.y; s.sx[2] = r0.z; s.sy[0] = r0.w; s.sy[1] = r1.x; s.sy[2] = r1.y;
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     const uint32_t first = a.slot_lo + (blockIdx.x * 256u + threadIdx.x) * a.spt;
     for (uint32_t si = 0; si < a.spt; ++si) {
         const uint32_t slot = first + si;
-        const SlotData sd = slot_load(a, slot);
+        const SlotData sd = slot_load(a, slot, !FILL);
         const int nt = sd.nx * sd.ny;
         const bool big = nt > 8;
         const int nt_small = big ? 0 : nt;
@@ -181,11 +183,17 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
         // phase 1: every wanted (tile, slot) pair into the table; packed[i] = entry | rank << 12 | wanted << 31
         uint32_t packed[8];
         int wtx = sd.tminx, wty = sd.tminy;                         // row-major walk of the tile bbox without integer division
+        uint32_t wmask = (FILL && nt_small) ? (uint32_t)a.want[slot] : 0u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             packed[i] = 0u;
             if (i < nt_small) {
-                const bool want = pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
+                bool want;
+                if (FILL) want = ((wmask >> i) & 1u) != 0u;
+                else {
+                    want = pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
+                    wmask |= want ? (1u << i) : 0u;
+                }
                 if (want) {
                     const uint32_t tile = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
                     uint32_t e = (tile * 0x9E3779B1u) >> 20;        // 12 bits
@@ -201,6 +209,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                 if (wtx >= sd.tminx + sd.nx) { wtx = sd.tminx; ++wty; }
             }
         }
+        if (!FILL && nt_small) a.want[slot] = (uint8_t)wmask;
         __syncthreads();
         // phase 2: one global atomic per distinct tile of the block
         for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) {
