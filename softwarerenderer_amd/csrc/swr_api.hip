@@ -401,11 +401,12 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     }
     {
         ScopedSpan sp(c, ST_SORT);
-        const unsigned ob = (n_tiles + 255u) / 256u;
+        const int band_tiles_y = c->band_ty1 - c->band_ty0;
+        const unsigned ob = (unsigned)(((c->tiles_x + 15) / 16) * ((band_tiles_y + 15) / 16));
         hipLaunchKernelGGL(k_tile_hist, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
-                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), n_tiles, order_hist, ctrl);
+                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), c->tiles_x, band_tiles_y, order_hist, ctrl);
         hipLaunchKernelGGL(k_tile_place, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
-                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), n_tiles, (const uint32_t*)order_hist,
+                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), c->tiles_x, band_tiles_y, (const uint32_t*)order_hist,
                            order_hist + SWR_ORDER_BUCKETS, tile_order, ctrl);
         SWR_HIP(c, hipGetLastError());
     }
@@ -426,10 +427,11 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.clear_color_on = cc ? 1 : 0;
         ra.clear_depth_on = cd ? 1 : 0;
         ra.tile_order = tile_order;
+        ra.n_tiles = n_tiles;
         ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
         ra.ctrl = ctrl;
         {
-            const dim3 g(n_tiles), t(64);                        // one wave per tile
+            const dim3 g((n_tiles + 511u) & ~511u), t(64);       // one wave per tile (grid in whole 8 x 64 XCD segments)
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
             const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
             bool phong = false, none = false, dust2_default = true;

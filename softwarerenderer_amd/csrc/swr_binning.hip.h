@@ -317,20 +317,32 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t w) {
 }
 __device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return frags + 16u * pairs; }
 
+// Thread i of the ordering kernels -> tile: a block takes a 16x16-tile region, a wave an 8x8 quarter of it, so that
+// tiles which end up next to each other in the order (same block, same bucket, consecutive LDS ranks) are neighbours
+// on screen: the raster kernel hands runs of 64 consecutive entries to one XCD, whose L2 then serves the triangle
+// records and vertices that neighbouring tiles share.  Returns 0xffffffff outside the band.
+__device__ __forceinline__ uint32_t order_tile_of_thread(int tiles_x, int tiles_y) {
+    const int sbx = (tiles_x + 15) >> 4;
+    const int bx = (int)(blockIdx.x % (uint32_t)sbx), by = (int)(blockIdx.x / (uint32_t)sbx);
+    const int t = threadIdx.x, q = t >> 6, w = t & 63;
+    const int tx = bx * 16 + (q & 1) * 8 + (w & 7), ty = by * 16 + (q >> 1) * 8 + (w >> 3);
+    return (tx < tiles_x && ty < tiles_y) ? (uint32_t)(ty * tiles_x + tx) : 0xffffffffu;
+}
+
 __global__ __launch_bounds__(256) void k_tile_hist(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
-                                                   uint32_t n, uint32_t* __restrict__ hist, const Ctrl* __restrict__ ctrl) {
+                                                   int tiles_x, int tiles_y, uint32_t* __restrict__ hist, const Ctrl* __restrict__ ctrl) {
     __shared__ uint32_t s_h[SWR_ORDER_BUCKETS];
     if (ctrl->poison) return;
     s_h[threadIdx.x] = 0u;
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) atomicAdd(&s_h[order_bucket(tile_weight(tile_work[i], tile_count[i]))], 1u);
+    const uint32_t i = order_tile_of_thread(tiles_x, tiles_y);
+    if (i != 0xffffffffu) atomicAdd(&s_h[order_bucket(tile_weight(tile_work[i], tile_count[i]))], 1u);
     __syncthreads();
     if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(256) void k_tile_place(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
-                                                    uint32_t n, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
+                                                    int tiles_x, int tiles_y, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
                                                     uint32_t* __restrict__ order, const Ctrl* __restrict__ ctrl) {
     __shared__ uint32_t s_suf[SWR_ORDER_BUCKETS];     // tiles in heavier buckets (descending order)
     __shared__ uint32_t s_cnt[SWR_ORDER_BUCKETS];     // this block's tiles per bucket, then their global base
@@ -345,9 +357,9 @@ __global__ __launch_bounds__(256) void k_tile_place(const uint32_t* __restrict__
         s_suf[t] += v;
         __syncthreads();
     }
-    const uint32_t i = blockIdx.x * 256u + t;
+    const uint32_t i = order_tile_of_thread(tiles_x, tiles_y);
     uint32_t b = 0, rank = 0;
-    if (i < n) {
+    if (i != 0xffffffffu) {
         b = order_bucket(tile_weight(tile_work[i], tile_count[i]));
         rank = atomicAdd(&s_cnt[b], 1u);
     }
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(256) void k_tile_place(const uint32_t* __restrict__
     __syncthreads();
     if (mine) s_cnt[t] = (s_suf[t] - hist[t]) + atomicAdd(&cursor[t], mine);
     __syncthreads();
-    if (i < n) order[s_cnt[b] + rank] = i;
+    if (i != 0xffffffffu) order[s_cnt[b] + rank] = i;
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------

@@ -18,7 +18,8 @@ struct RasterArgs {
     const uint32_t* __restrict__ tile_start;
     const uint32_t* __restrict__ tile_count;
     const uint4* __restrict__ pair_refs;       // per pair {slot, vertex refs of outputs[0..2]} (k_cover)
-    const uint32_t* __restrict__ tile_order;   // band-local tile index per workgroup
+    const uint32_t* __restrict__ tile_order;   // band-local tile indices, heaviest first (k_tile_place)
+    uint32_t n_tiles;
     float4* __restrict__ color;
     float* __restrict__ depth;
     uint32_t* __restrict__ tile_stats;     // 3 x u32 per tile: tested, shaded, written (accumulated)

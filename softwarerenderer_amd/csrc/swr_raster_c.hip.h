@@ -207,7 +207,16 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (a.ctrl->poison) return;
 
     const int lane = threadIdx.x & 63;
-    const uint32_t tile_o = a.tile_order[blockIdx.x];                     // heaviest tiles first (k_tile_place)
+    // Workgroups go round-robin to the 8 XCDs, in index order as slots free up.  The order array is cut in segments of
+    // 64 entries (neighbouring tiles of similar weight, see order_tile_of_thread); XCD x works through segments x, x+8, ...:
+    // still heaviest-first chip-wide (granularity 512 tiles), and a segment's shared triangle data stays in one L2.
+    uint32_t tile_o;
+    {
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        const uint32_t j = (((k >> 6) << 3) + xcd) * 64u + (k & 63u);
+        if (j >= a.n_tiles) return;
+        tile_o = a.tile_order[j];
+    }
     const int tx = (int)(tile_o % (uint32_t)a.fp.tiles_x), ty_local = (int)(tile_o / (uint32_t)a.fp.tiles_x);
     const int ty = a.fp.band_ty0 + ty_local;
     if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
