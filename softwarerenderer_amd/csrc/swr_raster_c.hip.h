@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (a.ctrl->poison) return;
 
     const int lane = threadIdx.x & 63;
+    constexpr bool HIZ = !LINES && (DT == SWR_DEPTH_LESS || DT == SWR_DEPTH_LESSEQUAL);    // every draw of the batch: depth only grows
     // Workgroups go round-robin to the 8 XCDs, in index order as slots free up.  The order array is cut in segments of
     // 64 entries (neighbouring tiles of similar weight, see order_tile_of_thread); XCD x works through segments x, x+8, ...:
     // still heaviest-first chip-wide (granularity 512 tiles), and a segment's shared triangle data stays in one L2.
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     uint32_t carry_key = 0xffffffffu;      // EARLYOUT: (pair, row) of the previous chunk's last fragment ...
     bool carry_dead = false;               // ... and whether that row segment has already hit its `break`
 #ifdef SWR_DEBUG_COUNTERS
-    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0;
+    unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0, dbg_hidden = 0;
 #endif
 
     for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
@@ -277,12 +278,69 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         //      the rest is staged in LDS compacted ----
         const uint32_t pidx = start + base + (uint32_t)lane;
         const uint4 ref = ref_next;
-        const int cnt = cnt_next;
+        const int cnt_in = cnt_next;
         {
             const uint32_t nb = base + (uint32_t)SWR_BATCH + (uint32_t)lane;
             ref_next = make_uint4(0u, 0u, 0u, 0u); cnt_next = 0;
             if (lane < SWR_BATCH && nb < n) { ref_next = a.pair_refs[start + nb]; cnt_next = (int)counts[start + nb]; }
         }
+        // one round trip: masks, TriRec and the three outputs of every non-empty pair
+        uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
+        float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
+        if (cnt_in > 0) {
+            m0 = masks[2 * (size_t)pidx]; m1 = masks[2 * (size_t)pidx + 1];
+            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
+            f0 = fq[0]; f1 = fq[1]; f2 = fq[2]; f3 = fq[3];
+        }
+        int cnt = cnt_in;
+        if (HIZ) {
+            // Hierarchical Z.  Under Less / LessEqual the stored depth of a pixel only grows, so the minimum over the
+            // tile at batch start bounds every later stored value from below.  A pair whose depth provably stays below
+            // it at every pixel of bbox /\ tile fails the depth test everywhere: the reference visits those fragments
+            // and writes nothing, so the pair is dropped here (its fragments still count as tested).
+            // Proof of the bound (u = 2^-24, R = bbox /\ tile, M_i as in pair_may_cover, S = sum |d_i invArea| M_i):
+            // every edge value of the reference's chain is within 35uM_i of the exact edge function (swr_binning.hip.h),
+            // so the fragment's float depth (two products, two sums) is within 39.3uS of the exact affine depth; that
+            // is maximal at a corner of R; the corners evaluated in float below are within 7.3uS; margin used: 64uS.
+            float zmin = 3.0e38f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int p = rr * 64 + lane;
+                const bool inb = x0 + (p & 15) < W && y0 + (p >> 4) < H;
+                zmin = fminf(zmin, inb ? L.z[p] : 3.0e38f);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, off));
+            if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE) {
+                const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
+                const float fxs = (float)max((int)(fbx & 0xffffu), x0), fxe = (float)min((int)(fbx >> 16), min(x0 + SWR_TILE - 1, W - 1));
+                const float fys = (float)max((int)(fby & 0xffffu), y0), fye = (float)min((int)(fby >> 16), min(y0 + SWR_TILE - 1, H - 1));
+                const float sx[3] = { f0.x, f0.y, f0.z }, sy[3] = { f0.w, f1.x, f1.y };
+                const float dd[3] = { f1.z, f1.w, f2.x };
+                const float inv_area = f2.y;
+                // edge k (weight of depths[k]): a12,b12 about vertex 1; a20,b20 about vertex 2; a01,b01 about vertex 0
+                const float ea[3] = { sy[1] - sy[2], sy[2] - sy[0], sy[0] - sy[1] };
+                const float eb[3] = { sx[2] - sx[1], sx[0] - sx[2], sx[1] - sx[0] };
+                const float rx[3] = { sx[1], sx[2], sx[0] }, ry[3] = { sy[1], sy[2], sy[0] };
+                float c00 = 0.f, c10 = 0.f, c01 = 0.f, c11 = 0.f, S = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float kk = dd[k] * inv_area;
+                    const float dxs = fxs - rx[k], dxe = fxe - rx[k], dys = fys - ry[k], dye = fye - ry[k];
+                    const float xs = ea[k] * dxs, xe = ea[k] * dxe, ys = eb[k] * dys, ye = eb[k] * dye;
+                    c00 += kk * (xs + ys); c10 += kk * (xe + ys); c01 += kk * (xs + ye); c11 += kk * (xe + ye);
+                    S += fabsf(kk) * (fabsf(ea[k]) * fmaxf(fabsf(dxs), fabsf(dxe)) + fabsf(eb[k]) * fmaxf(fabsf(dys), fabsf(dye)));
+                }
+                const float U = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) + S * (64.0f / 16777216.0f);
+                const bool finite = S < 1.0e30f && c00 == c00 && c10 == c10 && c01 == c01 && c11 == c11;   // fmaxf drops NaNs
+                const bool is_line = LINES && (__float_as_uint(f3.w) & SWR_FLAG_LINE) != 0u;
+                if (finite && !is_line && U < zmin) cnt = 0;
+            }
+        }
+        n_tested += (unsigned)cnt_in;
+#ifdef SWR_DEBUG_COUNTERS
+        dbg_hidden += (unsigned)(cnt_in - cnt);
+#endif
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         if (total == 0) continue;
@@ -290,9 +348,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
         if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
-            const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
-            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
-            const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
             const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
             const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + ref.z);
             const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + ref.w);
@@ -336,7 +391,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             L.pre[ci] = pre;
             if (ci > 0) atomicOr(&L.head[(pre - 1u) >> 5], 1u << ((pre - 1u) & 31u));
         }
-        n_tested += (unsigned)cnt;
 #ifdef SWR_DEBUG_COUNTERS
         ++dbg_batches;
 #endif
@@ -532,6 +586,11 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         atomicAdd(&a.dbg[4], (unsigned long long)dbg_chunk_lanes); atomicAdd(&a.dbg[3], (unsigned long long)dbg_chain);
         atomicAdd(&a.dbg[2], (unsigned long long)dbg_chain_c); atomicAdd(&a.dbg[5], (unsigned long long)dbg_sum_r);
         atomicAdd(&a.dbg[6], (unsigned long long)dbg_sum_c);
+    }
+    {
+        unsigned h = dbg_hidden;
+        for (int off = 32; off > 0; off >>= 1) h += (unsigned)__shfl_xor((int)h, off);
+        if (lane == 0 && a.dbg) atomicAdd(&a.dbg[7], (unsigned long long)h);
     }
 #endif
 }

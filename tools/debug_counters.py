@@ -19,12 +19,13 @@ try:
     r.render()
     dev._lib.swr_debug_counters(dev._ctx, out)
     st = dev.stats()
-    names = ["batches", "chunks", "max_col_steps", "max_row_steps", "chunk_lanes", "sum_row_steps", "sum_col_steps"]
+    names = ["batches", "chunks", "max_col_steps", "max_row_steps", "chunk_lanes", "sum_row_steps", "sum_col_steps", "hiz_hidden_fragments"]
     d = dict(zip(names, [int(v) for v in out]))
     print(cfg, d)
     print("pairs", st["tile_pairs"] // max(st["flushes"], 1), "batches", d["batches"], "chunks", d["chunks"],
           "fragments per chunk", d["chunk_lanes"] / max(d["chunks"], 1),
           "wave-max row steps per chunk", d["max_row_steps"] / max(d["chunks"], 1), "col", d["max_col_steps"] / max(d["chunks"], 1),
+          "fragments dropped by hi-Z", d.get("hiz_hidden_fragments", 0), "of depth-failing", st["fragments_tested"] // max(st["flushes"], 1) - st["fragments_shaded"] // max(st["flushes"], 1),
           "mean row steps per fragment", d["sum_row_steps"] / max(d["chunk_lanes"], 1), "col", d["sum_col_steps"] / max(d["chunk_lanes"], 1))
 finally:
     shutil.move(bak, lib)
