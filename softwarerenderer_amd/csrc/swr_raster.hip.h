@@ -25,6 +25,7 @@ struct RasterArgs {
     uint32_t* __restrict__ tile_stats;     // 3 x u32 per tile: tested, shaded, written (accumulated)
     float clear_rgba[4];
     int clear_color_on, clear_depth_on;
+    int depth_only_grows;                  // every draw of the batch tests Less or LessEqual (enables hi-Z in the generic kernels)
     unsigned long long* dbg;               // SWR_DEBUG_COUNTERS builds only: 8 accumulators
     const Ctrl* __restrict__ ctrl;         // poison guard (see Ctrl)
 };

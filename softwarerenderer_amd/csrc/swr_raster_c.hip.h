@@ -207,7 +207,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (a.ctrl->poison) return;
 
     const int lane = threadIdx.x & 63;
-    constexpr bool HIZ = !LINES && (DT == SWR_DEPTH_LESS || DT == SWR_DEPTH_LESSEQUAL);    // every draw of the batch: depth only grows
+    // hi-Z needs every draw of the batch to use Less / LessEqual (stored depth only grows): compile-time state, or the host's word
+    const bool HIZ = !LINES && (DT == SWR_DEPTH_LESS || DT == SWR_DEPTH_LESSEQUAL || (DT < 0 && a.depth_only_grows != 0));
     // Workgroups go round-robin to the 8 XCDs, in index order as slots free up.  The order array is cut in segments of
     // 64 entries (neighbouring tiles of similar weight, see order_tile_of_thread); XCD x works through segments x, x+8, ...:
     // still heaviest-first chip-wide (granularity 512 tiles), and a segment's shared triangle data stays in one L2.
