@@ -120,12 +120,54 @@ __device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot, b
     return s;
 }
 
-// Triangles spanning more than 8 tiles: spread over the wave one at a time (every lane must call).
+// Triangles spanning more than 8 tiles are spread over the wave, every lane a different tile (every lane must call).
+// Those of <= 64 tiles (one round of lanes) go four at a time: all four atomics are issued before any returned base is
+// used, so FILL pays one atomic round trip per four triangles instead of one each; larger ones take the plain loop.
 template <bool FILL>
 __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, uint32_t slot, bool big) {
     const int lane = threadIdx.x & 63;
     const int nt = sd.nx * sd.ny;
-    unsigned long long m = __ballot(big);
+    unsigned long long med = __ballot(big && nt <= 64);
+    while (med) {
+        bool want[4];
+        uint32_t tile[4], sslot[4], base[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            want[j] = false; tile[j] = 0u; sslot[j] = 0u; base[j] = 0u;
+            if (med) {                                             // wave-uniform
+                const int src = __ffsll((long long)med) - 1;
+                med &= med - 1;
+                const int s_tminx = __shfl(sd.tminx, src), s_tminy = __shfl(sd.tminy, src);
+                const int s_nx = __shfl(sd.nx, src), s_nt = __shfl(nt, src);
+                sslot[j] = (uint32_t)__shfl((int)slot, src);
+                float bsx[3], bsy[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sd.sx[k], src); bsy[k] = __shfl(sd.sy[k], src); }
+                const int bminX = __shfl(sd.minX, src), bmaxX = __shfl(sd.maxX, src), bminY = __shfl(sd.minY, src), bmaxY = __shfl(sd.maxY, src);
+                const bool b_line = __shfl((int)sd.is_line, src) != 0;
+                if (lane < s_nt) {
+                    const int ty = s_tminy + lane / s_nx, tx = s_tminx + lane % s_nx;
+                    want[j] = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
+                    tile[j] = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                }
+                if (want[j]) {
+                    if (FILL) base[j] = atomicAdd(&a.tile_count[tile[j]], 1u);
+                    else atomicAdd(&a.tile_count[tile[j]], 1u);
+                }
+            }
+        }
+        if (FILL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (want[j]) {
+                    const uint32_t at = a.tile_start[tile[j]] + base[j];
+                    if (at < a.list_capacity) a.tile_list[at] = sslot[j];
+                    else a.counters->overflow = 1u;
+                }
+            }
+        }
+    }
+    unsigned long long m = __ballot(big && nt > 64);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -137,7 +179,7 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
         for (int k = 0; k < 3; ++k) { bsx[k] = __shfl(sd.sx[k], src); bsy[k] = __shfl(sd.sy[k], src); }
         const int bminX = __shfl(sd.minX, src), bmaxX = __shfl(sd.maxX, src), bminY = __shfl(sd.minY, src), bmaxY = __shfl(sd.maxY, src);
         const bool b_line = __shfl((int)sd.is_line, src) != 0;
-        for (int i0 = 0; i0 < s_nt; i0 += 64) {      // one big triangle: every lane a different tile
+        for (int i0 = 0; i0 < s_nt; i0 += 64) {
             const int i = i0 + lane;
             bool want = i < s_nt;
             int ty = 0, tx = 0;

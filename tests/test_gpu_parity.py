@@ -245,3 +245,23 @@ def test_loaded_gltf_model_renders_like_the_oracle(device, tmp_path):
     assert len(model.Meshes) == 2 and all(m.Indices.size == len(idx) for m in model.Meshes)
     s = scenes.from_model(model, 400, 300, name="gltf_spheres")
     run_both(device, s)
+
+
+@pytest.mark.parametrize("depth_test", [DepthTest.Less, DepthTest.LessEqual])
+@pytest.mark.parametrize("program", [Program.Dust2LambertFog, Program.Gouraud])
+def test_hierarchical_z_exact_ties_and_occlusion(device, depth_test, program):
+    """The raster kernel drops pairs that provably fail the depth test (hi-Z).  Worst cases for that proof: the same
+    surfaces drawn twice (every fragment ties with the stored depth: passes under LessEqual, fails under Less), fully
+    occluded layers, and a near layer drawn first; with translucent vertex colours so that a wrongly dropped or kept
+    fragment changes the blended colour."""
+    base = scenes.cfg3(320, 256, (2, 2), (24, 12), tex_size=64, seed=91, program=program)
+    draws = []
+    for d in base.draws:
+        d.depth_test = depth_test
+        d.vertices = d.vertices.copy()
+        d.vertices["color"][:, 3] = 0.6
+    # near-to-far would hide everything behind the first layer; far-to-near nothing: use both orders plus exact repeats
+    draws = list(base.draws) + list(reversed(base.draws)) + list(base.draws[:2]) + list(base.draws[:2])
+    s = scenes.Scene(f"hiz_ties_{depth_test.name}_{program.name}", base.width, base.height, draws, textures=base.textures)
+    _, st = run_both(device, s)
+    assert st["fragments_tested"] > st["fragments_shaded"] > 0
