@@ -47,9 +47,43 @@ struct CoverArgs {
 template <bool LINES>
 __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     __shared__ uint16_t s_rows[256][18];      // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
+    __shared__ uint32_t s_hist[34];           // work sort: pairs per area bucket, then bucket bases
+    __shared__ uint16_t s_perm[256];          // sorted position -> thread whose pair it is
+    __shared__ uint16_t s_cnt[256];           // coverage counts back in pair order
     if (a.ctrl->poison) return;
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t p_own = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
+    // A lane's loop length is the area of bbox /\ tile (1..256 pixels) and a wave runs as long as its longest lane, so
+    // the block first sorts its 256 pairs by that area (counting sort in LDS): each wave then holds pairs of similar
+    // length.  Results are written at the pair's own index, so nothing downstream sees the permutation.
+    if (threadIdx.x < 34) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t bucket = 0, rank = 0;
+    {
+        int area = 0;
+        if (p_own < n_pairs) {
+            const uint32_t slot = a.tile_list[p_own], tile = a.pair_tile[p_own];
+            const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = a.fp.band_ty0 + (int)(tile / (uint32_t)a.fp.tiles_x);
+            const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
+            const float4 r3 = reinterpret_cast<const float4*>(a.recs + slot)[3];
+            const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
+            const int w = min((int)(bbx >> 16), min(x0 + SWR_TILE - 1, a.fp.width - 1)) - max((int)(bbx & 0xffffu), x0) + 1;
+            const int h = min((int)(bby >> 16), min(y0 + SWR_TILE - 1, a.fp.height - 1)) - max((int)(bby & 0xffffu), y0) + 1;
+            area = (w > 0 && h > 0) ? w * h : 0;
+        }
+        bucket = (uint32_t)(area + 7) >> 3;                      // 0..32
+        rank = atomicAdd(&s_hist[bucket], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int b = 32; b >= 0; --b) { const uint32_t c = s_hist[b]; s_hist[b] = acc; acc += c; }   // longest first
+    }
+    __syncthreads();
+    s_perm[s_hist[bucket] + rank] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    const uint32_t owner = s_perm[threadIdx.x];
+    const uint32_t p = blockIdx.x * 256u + owner;
     uint16_t* mrow16 = s_rows[threadIdx.x];
 #pragma unroll
     for (int i = 0; i < 16; ++i) mrow16[i] = 0;
@@ -138,11 +172,14 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
         a.counts[p] = (uint16_t)cnt;
     }
-    // raster scheduling weight: fragments per tile.  Pairs are sorted by tile, so a wave holds a few runs of equal
-    // tiles: one atomic per run (its last lane adds the run's sum, taken from a wave prefix sum).
+    s_cnt[owner] = (uint16_t)cnt;
+    __syncthreads();
+    // raster scheduling weight: fragments per tile.  Back in pair order (pairs are sorted by tile) a wave holds a few
+    // runs of equal tiles: one atomic per run (its last lane adds the run's sum, taken from a wave prefix sum).
     {
         const int lane = threadIdx.x & 63;
-        const uint32_t tile = p < n_pairs ? a.pair_tile[p] : 0xffffffffu;
+        cnt = (int)s_cnt[threadIdx.x];
+        const uint32_t tile = p_own < n_pairs ? a.pair_tile[p_own] : 0xffffffffu;
         const int incl = wave_incl_scan(cnt, lane);
         const uint32_t next_tile = (uint32_t)__shfl_down((int)tile, 1);
         const bool run_end = lane == 63 || next_tile != tile;
