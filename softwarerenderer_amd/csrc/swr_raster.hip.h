@@ -45,7 +45,7 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-#ifndef SWR_ABL_NOTEX
+#ifndef SWR_ABL_NOTEX          // tools/ablate.py timing experiments only (wrong image by design)
     if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
 #else
     tc.x = f.u; tc.y = f.v;
@@ -118,17 +118,11 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     const float4 a_uvn = V.a_uvn, b_uvn = V.b_uvn, c_uvn = V.c_uvn;
     if (simple && !interp) return a_col;                                                             // :622-627
 
-#ifdef SWR_ABL_NODIV
-    float ra = __fdividef(w0f, a_clip.w), rb = __fdividef(w1f, b_clip.w), rc = __fdividef(w2f, c_clip.w);
-    float inv_sum = (ra + rb) + rc;
-    float w = __fdividef(1.0f, inv_sum);
-#else
     float ra = w0f / a_clip.w;              // :576-578
     float rb = w1f / b_clip.w;
     float rc = w2f / c_clip.w;
     float inv_sum = (ra + rb) + rc;         // :579
     float w = 1.0f / inv_sum;               // :582
-#endif
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
     Frag f;
     if (interp) {
