@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--fake-world", type=int, default=0,
                     help="self-test of the N>1 code path in ONE process: act as rank 0 of N, collectives stubbed (numbers are meaningless)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not record hipEvents around kernels in the timed region")
+    ap.add_argument("--gather", choices=["rgb32f", "rgba32f"], default="rgb32f",
+                    help="N>1: what rank 0 gathers per frame -- rgb32f = the present payload of MainWindow.OnRender "
+                         "(Vector4 -> Vector3 flatten, 12 B/pixel), rgba32f = the raw colour buffer (16 B/pixel)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,9 +105,12 @@ def main():
         depth_t = [torch.zeros((rows, W), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
         window.SetBand(*band)
         window.BindFramebuffer(color_t[0].data_ptr(), depth_t[0].data_ptr())
-    frame_t = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    rgb = world > 1 and args.gather == "rgb32f"
+    chan = 3 if rgb else 4
+    rgb_t = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(len(color_t))] if rgb else None
+    frame_t = torch.empty((H, W, chan), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
     renderer = scenes.SceneRenderer(dev, scene, window=window)
-    state = {"i": 0, "pending": None}
+    state = {"i": 0, "pending": None, "render_s": 0.0}
 
     def wait_gather():
         if state["pending"] is not None:
@@ -127,10 +133,14 @@ def main():
         state["i"] += 1
         if len(color_t) > 1:
             window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
+        t_r = time.perf_counter()
         renderer.submit_frame()
+        if rgb:
+            window.FlattenTo(rgb_t[k].data_ptr())     # present payload: Vector4 -> Vector3 on the GPU (MainWindow.cs:234-240)
         dev.sync()            # the band must be final (optimistic flushes are validated here) before RCCL reads it
+        state["render_s"] += time.perf_counter() - t_r
         wait_gather()         # one gather in flight at a time (it fills the same frame on rank 0)
-        multigpu.gather_bands(color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+        multigpu.gather_bands(rgb_t[k] if rgb else color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
         if overlap:
             state["pending"] = k          # completes while the next frame renders into the other buffer
         else:
@@ -155,11 +165,13 @@ def main():
         dev.profile_reset()
         dev.profile_enable(2)          # hipEvents around the dominant kernel only: every event pair costs ~10 us of stream time
     barrier()
+    state["render_s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    render_s = state["render_s"]
     prof = dev.profile() if not args.no_profile_events else None
     st = dev.stats()
     stage_ms = None
@@ -177,11 +189,12 @@ def main():
 
     # whole-job numbers: max time over ranks, fragments summed over ranks
     counts = torch.tensor([st["fragments_tested"], st["fragments_written"], st["tile_pairs"]], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed, render_s], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+    elapsed = float(tmax[0].item())
+    render_s = float(tmax[1].item())
     frags_tested = counts[0].item() / args.steps
     frags_written = counts[1].item() / args.steps
     n_tris = scene.n_triangles
@@ -203,7 +216,7 @@ def main():
                                    f"{'2048^2 RGBA8 nearest texture, ' if scene.textures else ''}"
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
-                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL colour gather to rank 0"
+                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0"
                                       + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")},
             "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
             "fragments_tested_per_frame": int(frags_tested),
@@ -211,6 +224,12 @@ def main():
             "tile_pairs_per_frame": int(counts[2].item() / args.steps),
             "device": dev.name,
         }
+        if world > 1:
+            # the two legs of a multi-GPU step: rendering the bands (slowest rank, wall time until its band is final)
+            # and the xGMI gather of the frame into rank 0, which overlaps the next frame's rendering
+            out["multi_gpu"] = {"render_ms_per_step": round(1e3 * render_s / args.steps, 4),
+                                "gather_payload": args.gather,
+                                "gather_mb_per_frame_into_rank0": round(H * W * chan * 4 * (world - 1) / world / 1e6, 1)}
         if prof is not None and prof["raster_launches"] > 0:
             # dominant kernel = k_raster; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1)
             raster_ms = prof["raster_ms"] / prof["raster_launches"]

@@ -137,6 +137,10 @@ int  swr_readback(swr_context* ctx, float* color_rgba, float* depth);
 /* flush, then copy the colour band as packed RGB floats (12 B per pixel): the Vector4 -> Vector3 flatten of
  * MainWindow.OnRender (MainWindow.cs:234-240) done on the GPU, ready for glTexSubImage2D(RGB, FLOAT) */
 int  swr_readback_rgb(swr_context* ctx, float* rgb);
+/* same flatten, but into DEVICE memory supplied by the caller (band rows x W x 3 floats), enqueued after the recorded
+ * draws on the context's stream and NOT synchronised: swr_sync (or the caller's own stream order) completes it.  This is
+ * the present payload a multi-GPU frame gathers over xGMI (12 instead of 16 B per pixel). */
+int  swr_flatten_rgb_device(swr_context* ctx, float* d_rgb);
 /* upload caller memory into the band (tests: resume from a known framebuffer state) */
 int  swr_upload(swr_context* ctx, const float* color_rgba, const float* depth);
 int  swr_color_device_ptr(swr_context* ctx, void** out);

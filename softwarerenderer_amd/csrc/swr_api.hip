@@ -847,6 +847,23 @@ int swr_readback_rgb(swr_context* c, float* rgb) {
     return sync_locked(c);
 }
 
+int swr_flatten_rgb_device(swr_context* c, float* d_rgb) {
+    SWR_ENTER(c);
+    if (!d_rgb) return fail(c, SWR_ERR_INVALID_ARG, "d_rgb is null");
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    size_t n = band_pixels(c);
+    if (!n) return SWR_OK;
+    // stream order puts this after the frame's kernels; a batch that has to be replayed (optimistic flush) is replayed
+    // by the caller's swr_sync BEFORE the result is consumed -- and then the flatten must run again, which sync does
+    // not know about: so validate first (cheap when nothing overflowed: one pinned-flag read after the stream drains)
+    if ((rc = sync_locked(c))) return rc;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
+    hipLaunchKernelGGL(k_flatten_rgb, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->color, d_rgb, n);
+    SWR_HIP(c, hipGetLastError());
+    return SWR_OK;
+}
+
 int swr_upload(swr_context* c, const float* color, const float* depth) {
     SWR_ENTER(c);
     int rc = flush_locked(c);

@@ -290,6 +290,10 @@ class MainWindow:
             self._dev._ck(self._dev._lib.swr_readback_rgb(self._dev._ctx, out.ctypes.data))
         return out
 
+    def FlattenTo(self, device_ptr: int):
+        """FlatColorBuffer into caller-owned DEVICE memory (band rows x W x 3 floats); completes with Device.sync()."""
+        self._dev._ck(self._dev._lib.swr_flatten_rgb_device(self._dev._ctx, C.c_void_p(device_ptr)))
+
     def Upload(self, color=None, depth=None):
         c = np.ascontiguousarray(color, dtype=np.float32) if color is not None else None
         d = np.ascontiguousarray(depth, dtype=np.float32) if depth is not None else None

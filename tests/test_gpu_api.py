@@ -310,3 +310,25 @@ def test_device_side_frustum_culling_equals_host_side_decision(device, oracle_li
     assert_frame_parity(c, dz, o.color, o.depth, 1, "frustum-culled frame")
     for k in ("triangles_in", "triangles_setup", "fragments_tested", "fragments_written"):
         assert st[k] == rst[k], (k, st[k], rst[k])
+
+
+def test_device_side_rgb_flatten_equals_host_readback(device):
+    """swr_flatten_rgb_device (the payload a multi-GPU frame gathers) == ColorBuffer[..., :3], bit for bit.
+    The device buffer comes straight from the HIP runtime the library already loaded (no torch in this process)."""
+    hip = C.CDLL("libamdhip64.so")
+    s = scenes.cfg2(200, 120, 300, seed=12)
+    r = scenes.SceneRenderer(device, s)
+    r.submit_frame()
+    nbytes = s.height * s.width * 3 * 4
+    dptr = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dptr), C.c_size_t(nbytes)) == 0
+    try:
+        r.window.FlattenTo(dptr.value)
+        device.sync()
+        got = np.empty((s.height, s.width, 3), dtype=np.float32)
+        assert hip.hipMemcpy(C.c_void_p(got.ctypes.data), dptr, C.c_size_t(nbytes), 2) == 0      # hipMemcpyDeviceToHost
+    finally:
+        hip.hipFree(dptr)
+    c = r.window.ColorBuffer
+    r.close()
+    assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(c[..., :3]).view(np.uint32))
