@@ -2,7 +2,8 @@
 //
 // A context records draws (Rasterizer.RenderMesh calls, Rasterizer.cs:163-174) in submission order
 // and executes them as ONE batch per flush:
-//     k_vertex -> k_setup -> k_bin<count> -> k_scan -> k_bin<fill> -> k_sort_tiles -> k_raster
+//     [k_frustum_cull ->] k_vertex -> k_setup -> k_bin<count> -> k_scan_sums/apply -> k_bin<fill> -> k_sort_tiles
+//     -> k_cover -> k_tile_hist/place -> k_raster_c
 // There is no CPU fallback anywhere in this file: every pixel is produced by the HIP kernels.
 #include <hip/hip_runtime.h>
 

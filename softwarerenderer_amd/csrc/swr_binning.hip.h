@@ -8,6 +8,8 @@
 //   k_scan        : exclusive scan -> tile_start, total pairs
 //   k_bin<FILL>   : list[tile_start + atomic cursor] = slot       (arbitrary order inside a tile)
 //   k_sort_tiles  : one wave per tile sorts its segment ascending (restores submission order)
+// plus, after k_cover has counted the fragments of every tile:
+//   k_tile_hist / k_tile_place : counting sort of the tiles by descending work -> the raster kernel's dispatch order
 #pragma once
 #include "swr_device.h"
 

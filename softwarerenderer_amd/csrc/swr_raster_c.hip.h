@@ -14,6 +14,10 @@
 //   colour/Z update (tile-resident in LDS) are order-independent inside a chunk, and chunks run in stream order
 //   = the serial schedule of the reference (>= ties, blending, alpha-gated Z writes all exact).  Each fragment
 //   lane recomputes its own edge values by replaying its (y-startY)+(x-startX) add chain at full lane utilisation.
+//   Pairs are taken 16 at a time: one lane per pair fetches the triangle record and the three outputs ONCE and
+//   stages what fragments need in LDS (per-fragment gathers through the vector L1 were the first bound), pairs that
+//   provably fail the depth test everywhere are dropped against the tile's minimum stored depth (hi-Z), and tiles
+//   are dispatched heaviest first (k_tile_hist / k_tile_place in swr_binning.hip.h).
 #pragma once
 #include "swr_device.h"
 #include "swr_raster.hip.h"
