@@ -141,6 +141,11 @@ int  swr_readback_rgb(swr_context* ctx, float* rgb);
  * draws on the context's stream and NOT synchronised: swr_sync (or the caller's own stream order) completes it.  This is
  * the present payload a multi-GPU frame gathers over xGMI (12 instead of 16 B per pixel). */
 int  swr_flatten_rgb_device(swr_context* ctx, float* d_rgb);
+/* Page-lock a long-lived host buffer (the C# side's pinned ColorBuffer / flatColorBuffer arrays) so that swr_readback /
+ * swr_readback_rgb / swr_upload DMA straight into it at PCIe rate instead of going through a pageable staging copy.
+ * Optional: unregistered buffers work, only slower.  Unregister before freeing the memory. */
+int  swr_host_register(swr_context* ctx, void* ptr, size_t bytes);
+int  swr_host_unregister(swr_context* ctx, void* ptr);
 /* upload caller memory into the band (tests: resume from a known framebuffer state) */
 int  swr_upload(swr_context* ctx, const float* color_rgba, const float* depth);
 int  swr_color_device_ptr(swr_context* ctx, void** out);

@@ -848,6 +848,23 @@ int swr_readback_rgb(swr_context* c, float* rgb) {
     return sync_locked(c);
 }
 
+int swr_host_register(swr_context* c, void* ptr, size_t bytes) {
+    SWR_ENTER(c);
+    if (!ptr || !bytes) return fail(c, SWR_ERR_INVALID_ARG, "null or empty host buffer");
+    SWR_HIP(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return SWR_OK;
+}
+
+int swr_host_unregister(swr_context* c, void* ptr) {
+    SWR_ENTER(c);
+    if (!ptr) return fail(c, SWR_ERR_INVALID_ARG, "null host buffer");
+    int rc = flush_locked(c);                       // nothing in flight may still target the buffer
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    SWR_HIP(c, hipHostUnregister(ptr));
+    return SWR_OK;
+}
+
 int swr_flatten_rgb_device(swr_context* c, float* d_rgb) {
     SWR_ENTER(c);
     if (!d_rgb) return fail(c, SWR_ERR_INVALID_ARG, "d_rgb is null");

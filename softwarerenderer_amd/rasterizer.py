@@ -126,6 +126,13 @@ class Device:
         self._ck(self._lib.swr_device_name(self._ctx, buf, 256))
         return buf.value.decode()
 
+    def pin(self, array: np.ndarray):
+        """Page-lock a long-lived host array (swr_host_register): read-backs into it then DMA at PCIe rate."""
+        self._ck(self._lib.swr_host_register(self._ctx, C.c_void_p(array.ctypes.data), C.c_size_t(array.nbytes)))
+
+    def unpin(self, array: np.ndarray):
+        self._ck(self._lib.swr_host_unregister(self._ctx, C.c_void_p(array.ctypes.data)))
+
     def stats(self) -> dict:
         s = N.Stats()
         self._ck(self._lib.swr_get_stats(self._ctx, C.byref(s)))
@@ -282,10 +289,16 @@ class MainWindow:
     def DepthBuffer(self) -> np.ndarray:
         return self._read(False, True)[1]
 
-    def FlatColorBuffer(self) -> np.ndarray:
-        """The Vector3[] `flatColorBuffer` of MainWindow.OnRender (MainWindow.cs:234-240), flattened on the GPU."""
+    def FlatColorBuffer(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """The Vector3[] `flatColorBuffer` of MainWindow.OnRender (MainWindow.cs:234-240), flattened on the GPU.
+        `out`: a caller-owned (rows, W, 3) float32 array to fill -- page-lock it once with Device.pin() and the copy runs
+        at PCIe rate."""
         _, rows = self.band_pixel_rows()
-        out = np.empty((rows, max(self.RenderWidth, 0), 3), dtype=np.float32)
+        shape = (rows, max(self.RenderWidth, 0), 3)
+        if out is None:
+            out = np.empty(shape, dtype=np.float32)
+        elif out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {shape}")
         if out.size:
             self._dev._ck(self._dev._lib.swr_readback_rgb(self._dev._ctx, out.ctypes.data))
         return out

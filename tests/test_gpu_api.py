@@ -332,3 +332,22 @@ def test_device_side_rgb_flatten_equals_host_readback(device):
     c = r.window.ColorBuffer
     r.close()
     assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(c[..., :3]).view(np.uint32))
+
+
+def test_pinned_host_buffer_readback(device):
+    """swr_host_register: the same bytes arrive in a page-locked caller buffer; wrong shapes are refused."""
+    s = scenes.cfg2(160, 96, 200, seed=13)
+    r = scenes.SceneRenderer(device, s)
+    r.submit_frame()
+    ref = r.window.FlatColorBuffer()
+    out = np.zeros_like(ref)
+    device.pin(out)
+    try:
+        r.submit_frame()
+        got = r.window.FlatColorBuffer(out=out)
+        assert got is out and np.array_equal(out.view(np.uint32), ref.view(np.uint32))
+    finally:
+        device.unpin(out)
+    with pytest.raises(ValueError):
+        r.window.FlatColorBuffer(out=np.zeros((3, 3, 3), dtype=np.float32))
+    r.close()
