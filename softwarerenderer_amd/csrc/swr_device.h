@@ -224,7 +224,18 @@ __device__ __forceinline__ bool line_test(float p0x, float p0y, float p1x, float
 }
 
 // Texture.Sample, Texture.cs:43-63 -- nearest, wrap; texels RGBA8 row-major
-__device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
+// Texture.Sample in two halves, so that a caller can put independent work between the texel load and its use
+// (k_raster_c: the fetch is a dependent gather with a long latency)
+__device__ __forceinline__ float4 texture_unpack(uint32_t p) {              // Texture.cs:55-62: byte * (1f / 255f)
+    const float inv255 = 1.0f / 255.0f;
+    float4 o;
+    o.x = (float)(p & 0xffu) * inv255;
+    o.y = (float)((p >> 8) & 0xffu) * inv255;
+    o.z = (float)((p >> 16) & 0xffu) * inv255;
+    o.w = (float)(p >> 24) * inv255;
+    return o;
+}
+__device__ __forceinline__ size_t texture_nearest_index(int w, int h, float tu, float tv) {      // Texture.cs:43-54
     float u = tu - (float)f2i(tu);
     float v = tv - (float)f2i(tv);
     u += (u < 0) ? 1.0f : 0.0f;
@@ -236,14 +247,10 @@ __device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex
     int y = (yi >= 0 && yi < h) ? yi : (yi == h ? 0 : yi % h);
     if (x < 0) x += w;
     if (y < 0) y += h;
-    uint32_t p = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)y * (size_t)w + (size_t)x));
-    const float inv255 = 1.0f / 255.0f;
-    float4 o;
-    o.x = (float)(p & 0xffu) * inv255;
-    o.y = (float)((p >> 8) & 0xffu) * inv255;
-    o.z = (float)((p >> 16) & 0xffu) * inv255;
-    o.w = (float)(p >> 24) * inv255;
-    return o;
+    return (size_t)y * (size_t)w + (size_t)x;
+}
+__device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
+    return texture_unpack(reinterpret_cast<const uint32_t*>(tex)[texture_nearest_index(w, h, tu, tv)]);
 }
 
 // BUILD-DEFINED bilinear filter with wrap (row N4; no reference semantics -- the formula is stated in

@@ -35,6 +35,8 @@ struct Frag {
     float clip_z;
     float4 color;
     float u, v;
+    uint32_t texel;        // nearest filter: the RGBA8 texel, loaded as early as u,v are known (see shade_fragment)
+    bool texel_loaded;
     float wn[3];
     float wpos[3];
 };
@@ -42,18 +44,20 @@ struct Frag {
 // Renderer.FragmentShader, Renderer.cs:848-860
 __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, const Frag& f) {
     const swr_uniforms& u = dp->u;
+    // everything that does not need the texel first (its load is in flight, see shade_fragment)
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
+    float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
+    fog = (fog * fog) * (3.0f - 2.0f * fog);
+    float s = 0.1f + 0.9f * diffuse;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 #ifndef SWR_ABL_NOTEX          // tools/ablate.py timing experiments only (wrong image by design)
-    if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    if (f.texel_loaded) tc = texture_unpack(f.texel);
+    else if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
 #else
     tc.x = f.u; tc.y = f.v;
 #endif
     float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
-    float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
-    fog = (fog * fog) * (3.0f - 2.0f * fog);
-    float s = 0.1f + 0.9f * diffuse;
     float4 o;
     o.x = nm_lerp(u.fog_color[0], (base.x * s) * u.light_color[0], fog);
     o.y = nm_lerp(u.fog_color[1], (base.y * s) * u.light_color[1], fog);
@@ -66,7 +70,8 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
 __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, const Frag& f) {
     const swr_uniforms& u = dp->u;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-    if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    if (f.texel_loaded) tc = texture_unpack(f.texel);
+    else if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
     float base[4] = { f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w };
     float Vd[3] = { u.camera_position[0] - f.wpos[0], u.camera_position[1] - f.wpos[1], u.camera_position[2] - f.wpos[2] };
     float vl = sqrtf(dot3(Vd[0], Vd[1], Vd[2], Vd[0], Vd[1], Vd[2]));
@@ -125,17 +130,29 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     float w = 1.0f / inv_sum;               // :582
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
     Frag f;
+    if (simple) {
+        return make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
+                           SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));     // interp (see above)
+    }
+    f.u = SWR_PERSP(a_uvn.x, b_uvn.x, c_uvn.x);
+    f.v = SWR_PERSP(a_uvn.y, b_uvn.y, c_uvn.y);
+    // The texel fetch is a dependent gather with a long latency: issue it as soon as u,v exist; the rest of the
+    // interpolation, the normal and the fog term run while it is in flight.  (Bilinear textures fetch in the program.)
+    f.texel = 0u; f.texel_loaded = false;
+#ifndef SWR_ABL_NOTEX
+    if (dp->tex && dp->tex_h > 0) {
+        f.texel = reinterpret_cast<const uint32_t*>(dp->tex)[texture_nearest_index(dp->tex_w, dp->tex_h, f.u, f.v)];
+        f.texel_loaded = true;
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
+#endif
     if (interp) {
         f.color = make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
                               SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));
     } else {
         f.color = a_col;
     }
-    if (simple) return f.color;
-
     f.clip_z = SWR_PERSP(a_clip.z, b_clip.z, c_clip.z);
-    f.u = SWR_PERSP(a_uvn.x, b_uvn.x, c_uvn.x);
-    f.v = SWR_PERSP(a_uvn.y, b_uvn.y, c_uvn.y);
 #undef SWR_PERSP
     if (interp) {
         float wa = ra * w, wb = rb * w, wc = rc * w;      // :583-585
