@@ -206,6 +206,9 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #define SWR_RASTER_MINWAVES 4
 #endif
 #define SWR_BATCH_FRAGS (SWR_BATCH * 256)      // a pair covers <= 256 pixels
+#ifndef SWR_WINDOW
+#define SWR_WINDOW 32                          // candidate pairs examined per batch (<= 64)
+#endif
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
@@ -286,11 +289,13 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     const int W = a.fp.width, H = a.fp.height;
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
 
-    // pair references and counts are fetched one batch ahead, so a batch set-up is ONE memory round trip
-    // (masks, TriRec and the three outputs are then independent loads)
-    uint4 ref_next = make_uint4(0u, 0u, 0u, 0u);
-    int cnt_next = 0;
-    if (lane < SWR_BATCH && (uint32_t)lane < n) { ref_next = a.pair_refs[start + (uint32_t)lane]; cnt_next = (int)counts[start + (uint32_t)lane]; }
+    // A sliding window of SWR_WINDOW candidate pairs (lane i holds entry base + i of the tile list: references and
+    // count, fetched while the previous batch is rasterised).  Each batch stages the first SWR_BATCH candidates that
+    // survive (non-empty, not hidden by hi-Z) and consumes the list up to the last of them, so batches are full
+    // although a third of the candidates drops out.
+    uint4 ref_w = make_uint4(0u, 0u, 0u, 0u);
+    int cnt_w = 0;
+    if (lane < SWR_WINDOW && (uint32_t)lane < n) { ref_w = a.pair_refs[start + (uint32_t)lane]; cnt_w = (int)counts[start + (uint32_t)lane]; }
 
     // ---- tile init: clear fused, or one coalesced read of the framebuffer ----
 #pragma unroll
@@ -315,17 +320,14 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0, dbg_hidden = 0;
 #endif
 
-    for (uint32_t base = 0; base < n; base += (uint32_t)SWR_BATCH) {
-        // ---- batch: the next (up to) SWR_BATCH pairs of this tile; empty pairs (binning is conservative) are dropped,
-        //      the rest is staged in LDS compacted ----
+    uint32_t batch_no = 0;
+    for (uint32_t base = 0; base < n; ++batch_no) {
+        // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
+        //      of the window are staged in LDS ----
         const uint32_t pidx = start + base + (uint32_t)lane;
-        const uint4 ref = ref_next;
-        const int cnt_in = cnt_next;
-        {
-            const uint32_t nb = base + (uint32_t)SWR_BATCH + (uint32_t)lane;
-            ref_next = make_uint4(0u, 0u, 0u, 0u); cnt_next = 0;
-            if (lane < SWR_BATCH && nb < n) { ref_next = a.pair_refs[start + nb]; cnt_next = (int)counts[start + nb]; }
-        }
+        const uint4 ref = ref_w;
+        const bool in_window = lane < SWR_WINDOW && base + (uint32_t)lane < n;
+        const int cnt_in = in_window ? cnt_w : 0;
         // one round trip: masks, TriRec and the three outputs of every non-empty pair
         uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
         float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
@@ -379,10 +381,32 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 if (finite && !is_line && U < zmin) cnt = 0;
             }
         }
-        n_tested += (unsigned)cnt_in;
+        // take the first SWR_BATCH survivors; the list is consumed up to and including the last one taken
+        int consumed;
+        {
+            const unsigned long long surv = __ballot(cnt > 0);
+            const int rank = __popcll(surv & ((1ull << lane) - 1ull));
+            const unsigned long long last = __ballot(cnt > 0 && rank == SWR_BATCH - 1);
+            consumed = last ? __ffsll((long long)last) : min(SWR_WINDOW, (int)(n - base));
+            if (lane >= consumed) cnt = 0;
+        }
+        const int cnt_seen = lane < consumed ? cnt_in : 0;
+        n_tested += (unsigned)cnt_seen;
 #ifdef SWR_DEBUG_COUNTERS
-        dbg_hidden += (unsigned)(cnt_in - cnt);
+        dbg_hidden += (unsigned)(cnt_seen - cnt);
 #endif
+        // slide the window: what was not consumed moves down, the freed lanes fetch the next entries of the list
+        base += (uint32_t)consumed;
+        {
+            const int src = lane + consumed;
+            uint4 r2;
+            r2.x = (uint32_t)__shfl((int)ref_w.x, src); r2.y = (uint32_t)__shfl((int)ref_w.y, src);
+            r2.z = (uint32_t)__shfl((int)ref_w.z, src); r2.w = (uint32_t)__shfl((int)ref_w.w, src);
+            const int c2 = __shfl(cnt_w, src);
+            ref_w = r2; cnt_w = c2;
+            const uint32_t e = base + (uint32_t)lane;
+            if (lane >= SWR_WINDOW - consumed && lane < SWR_WINDOW && e < n) { ref_w = a.pair_refs[start + e]; cnt_w = (int)counts[start + e]; }
+        }
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __shfl(cincl, 63);
         if (total == 0) continue;
@@ -564,7 +588,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 // "any failure to my left" over lanes; a segment cut by the chunk boundary carries its state over.
                 bool killed = false;
                 const bool none = f_blend == SWR_BLEND_NONE;                       // uniform: a chunk holds one draw
-                const uint32_t key = ((base + (uint32_t)t) << 4) | (uint32_t)(pix >> 4);
+                const uint32_t key = ((batch_no * (uint32_t)SWR_BATCH + (uint32_t)t) << 4) | (uint32_t)(pix >> 4);   // unique per (pair, row)
                 if (none) {
                     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
                     const bool head = act && (lane == 0 || key != prev);
