@@ -24,13 +24,28 @@
 
 namespace swr {
 
+// Inclusive prefix sum over the wave, on the DPP path (no LDS round trips): Hillis-Steele inside each row of 16 lanes
+// with row_shr, then the row totals with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3).  All 64 lanes must be active.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31
     return v;
+}
+// minimum over the wave (same DPP ladder; the last lane ends up with the result)
+__device__ __forceinline__ float wave_min(float x) {
+    const int big = __float_as_int(3.0e38f);
+    int v = __float_as_int(x);
+#define SWR_MIN_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(big, v, ctrl, rows, 0xf, false); \
+                                   v = __float_as_int(fminf(__int_as_float(v), __int_as_float(t))); }
+    SWR_MIN_STEP(0x111, 0xf) SWR_MIN_STEP(0x112, 0xf) SWR_MIN_STEP(0x114, 0xf) SWR_MIN_STEP(0x118, 0xf)
+    SWR_MIN_STEP(0x142, 0xa) SWR_MIN_STEP(0x143, 0xc)
+#undef SWR_MIN_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
 
 struct CoverArgs {
@@ -353,8 +368,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 const bool inb = x0 + (p & 15) < W && y0 + (p >> 4) < H;
                 zmin = fminf(zmin, inb ? L.z[p] : 3.0e38f);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) zmin = fminf(zmin, __shfl_xor(zmin, off));
+            zmin = wave_min(zmin);
             if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE) {
                 const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
                 const float fxs = (float)max((int)(fbx & 0xffffu), x0), fxe = (float)min((int)(fbx >> 16), min(x0 + SWR_TILE - 1, W - 1));
