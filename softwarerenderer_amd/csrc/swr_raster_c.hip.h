@@ -422,7 +422,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             if (lane >= SWR_WINDOW - consumed && lane < SWR_WINDOW && e < n) { ref_w = a.pair_refs[start + e]; cnt_w = (int)counts[start + e]; }
         }
         const int cincl = wave_incl_scan(cnt, lane);
-        const int total = __shfl(cincl, 63);
+        const int total = __builtin_amdgcn_readlane(cincl, 63);
         if (total == 0) continue;
         const unsigned long long nzb = __ballot(cnt > 0);
         const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
@@ -650,12 +650,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         }
     }
 
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        n_tested += (unsigned)__shfl_xor((int)n_tested, off);
-        n_shaded += (unsigned)__shfl_xor((int)n_shaded, off);
-        n_written += (unsigned)__shfl_xor((int)n_written, off);
-    }
+    n_tested = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_tested, lane), 63);
+    n_shaded = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_shaded, lane), 63);
+    n_written = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_written, lane), 63);
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;
         atomicAdd(&ts[0], n_tested); atomicAdd(&ts[1], n_shaded); atomicAdd(&ts[2], n_written);     // no return value: no round trip
