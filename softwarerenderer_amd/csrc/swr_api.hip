@@ -435,8 +435,10 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
             const dim3 g((n_tiles + 511u) & ~511u), t(64);       // one wave per tile (grid in whole 8 x 64 XCD segments)
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
             const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
-            bool phong = false, none = false, dust2_default = true, grows = true, phong_default = true;
+            bool phong = false, none = false, dust2_default = true, grows = true, phong_default = true, gouraud_default = true;
             for (auto& d : b.draws) {
+                gouraud_default = gouraud_default && d.p.program == SWR_PROG_GOURAUD &&
+                                  d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
                 phong_default = phong_default && d.p.program == SWR_PROG_PHONG_4POINT &&
                                 d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
                 grows = grows && (d.p.depth_test == SWR_DEPTH_LESS || d.p.depth_test == SWR_DEPTH_LESSEQUAL);
@@ -454,6 +456,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
             else if (phong) hipLaunchKernelGGL((k_raster_c<false, true>), g, t, 0, c->stream, ra, mk, pc);
             else if (dust2_default)
                 hipLaunchKernelGGL((k_raster_c<false, false, SWR_PROG_DUST2_LAMBERT_FOG, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
+            else if (gouraud_default)
+                hipLaunchKernelGGL((k_raster_c<false, false, SWR_PROG_GOURAUD, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
             else hipLaunchKernelGGL((k_raster_c<false, false>), g, t, 0, c->stream, ra, mk, pc);
         }
         SWR_HIP(c, hipGetLastError());
