@@ -317,6 +317,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     ba.ctrl = c->d_ctrl.as<Ctrl>();
     ba.total = c->d_total.as<unsigned long long>();
     ba.want = c->d_want.as<uint8_t>();
+    ba.tpw = 64u;
     return ba;
 }
 
@@ -330,8 +331,10 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     uint32_t* tile_order = tile_work + n_tiles;
     uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
     BinArgs ba = make_bin_args(c, b, lo, hi);
-    const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;
-    const uint32_t bin_blocks = (bin_threads + 255u) / 256u;
+    const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;          // = triangles
+    ba.tpw = 64u;                                                            // aim for >= ~1000 waves
+    while (ba.tpw > 4u && bin_threads < ba.tpw * 1024u) ba.tpw >>= 1;
+    const uint32_t bin_blocks = (bin_threads + 4u * ba.tpw - 1u) / (4u * ba.tpw);
     {
         ScopedSpan sp(c, ST_BIN);
         SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));

@@ -34,6 +34,8 @@ struct BinArgs {
     const Ctrl* __restrict__ ctrl;
     const unsigned long long* __restrict__ total;
     uint8_t* __restrict__ want;          // per slot: which of its (<= 8) tiles passed pair_may_cover -- written by COUNT, read by FILL
+    uint32_t tpw;                        // triangles per wave: 64, or fewer for small batches (a wave works through its big
+                                         // triangles one after the other: with few triangles more, emptier waves finish sooner)
 };
 
 // Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
@@ -214,9 +216,11 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && a.ctrl->poison) return;
-    const uint32_t first = a.slot_lo + (blockIdx.x * 256u + threadIdx.x) * a.spt;
+    const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6, lane_id = threadIdx.x & 63u;
+    const bool has_tri = lane_id < a.tpw;
+    const uint32_t first = a.slot_lo + (wave_id * a.tpw + lane_id) * a.spt;
     for (uint32_t si = 0; si < a.spt; ++si) {
-        const uint32_t slot = first + si;
+        const uint32_t slot = has_tri ? first + si : 0xffffffffu;          // >= slot_hi: nothing
         const SlotData sd = slot_load(a, slot, !FILL);
         const int nt = sd.nx * sd.ny;
         const bool big = nt > 8;
