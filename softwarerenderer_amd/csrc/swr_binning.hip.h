@@ -210,7 +210,11 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
 // keyed by tile -- neighbouring triangles share tiles, so 256 triangles touch few distinct ones -- and only one
 // global atomic per distinct tile leaves the block; FILL gets each pair's rank from the LDS add and the tile's base
 // from that one global atomic.  The order inside a tile's list is irrelevant here (k_sort_tiles restores it).
-#define SWR_BIN_TABLE 4096          // >= 2 x (256 threads x 8 tiles): open addressing always terminates
+#ifndef SWR_BIN_TABLE_LOG2
+#define SWR_BIN_TABLE_LOG2 9
+#endif
+#define SWR_BIN_TABLE (1 << SWR_BIN_TABLE_LOG2)     // a block rarely touches more than a few hundred distinct tiles; probing is bounded and
+                                                  // a pair that finds no slot goes to the global counter directly
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
@@ -244,14 +248,23 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                 }
                 if (want) {
                     const uint32_t tile = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
-                    uint32_t e = (tile * 0x9E3779B1u) >> 20;        // 12 bits
-                    for (;;) {
+                    uint32_t e = (tile * 0x9E3779B1u) >> (32 - SWR_BIN_TABLE_LOG2);
+                    bool placed = false;
+                    for (int probe = 0; probe < 16; ++probe) {
                         const uint32_t prev = atomicCAS(&s_key[e], 0u, tile + 1u);
-                        if (prev == 0u || prev == tile + 1u) break;
+                        if (prev == 0u || prev == tile + 1u) { placed = true; break; }
                         e = (e + 1u) & (SWR_BIN_TABLE - 1u);
                     }
-                    const uint32_t rank = atomicAdd(&s_val[e], 1u);       // < 2048
-                    packed[i] = e | (rank << 12) | 0x80000000u;
+                    if (placed) {
+                        const uint32_t rank = atomicAdd(&s_val[e], 1u);       // < 2048
+                        packed[i] = e | (rank << 12) | 0x80000000u;
+                    } else if (FILL) {                                      // crowded table (many distinct tiles): go direct
+                        const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
+                        if (at < a.list_capacity) a.tile_list[at] = slot;
+                        else a.counters->overflow = 1u;
+                    } else {
+                        atomicAdd(&a.tile_count[tile], 1u);
+                    }
                 }
                 ++wtx;
                 if (wtx >= sd.tminx + sd.nx) { wtx = sd.tminx; ++wty; }
