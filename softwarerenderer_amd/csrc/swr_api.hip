@@ -344,7 +344,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
         // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
         const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
-        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count,
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, ba.tile_count,
                            c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
                            cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
                            mode == MODE_ASYNC ? 1 : 0, tile_work, order_hist);
@@ -375,8 +375,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     }
     {
         ScopedSpan sp(c, ST_BIN);
-        SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
-        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
+        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);       // cursors were zeroed by k_scan_apply
         SWR_HIP(c, hipGetLastError());
     }
     {

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__
     if (threadIdx.x == 0) sums[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict__ count, uint32_t* __restrict__ start,
+__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ count, uint32_t* __restrict__ start,
                                                      uint32_t n, const unsigned long long* __restrict__ sums,
                                                      unsigned long long* __restrict__ total_out,
                                                      unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
@@ -349,7 +349,10 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
     unsigned long long wave_off = 0;
     for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
     const unsigned long long excl = off + wave_off + incl - c;
-    if (i < n) start[i] = (uint32_t)min(excl, 0xffffffffull);
+    if (i < n) {
+        start[i] = (uint32_t)min(excl, 0xffffffffull);
+        count[i] = 0u;              // k_bin<FILL> uses the counts as cursors and rebuilds them: no separate clear
+    }
     if (blockIdx.x == gridDim.x - 1 && tid == 1023u) {
         const unsigned long long total = excl + c;
         *total_out = total;
