@@ -265,3 +265,17 @@ def test_hierarchical_z_exact_ties_and_occlusion(device, depth_test, program):
     s = scenes.Scene(f"hiz_ties_{depth_test.name}_{program.name}", base.width, base.height, draws, textures=base.textures)
     _, st = run_both(device, s)
     assert st["fragments_tested"] > st["fragments_shaded"] > 0
+
+
+def test_hand_derived_kat_scenes_on_the_gpu(device):
+    """The hand-derived known answers of tests/test_oracle_kat.py hold for the HIP path too (exact constants, no oracle)."""
+    from test_oracle_kat import _cfg1_dust2
+    for args, px, expect in (((0.0, 1.0, 0.0), (128, 128), (0.25, 0.25, 0.5, 1.0)),
+                             ((0.0, 2.0, 1.0), (128, 128), (0.625, 0.375, 0.375, 1.0)),
+                             ((0.0, 0.5, 1.0), (128, 128), (1.0, 0.5, 0.25, 1.0))):
+        s = _cfg1_dust2(*args)
+        r = scenes.SceneRenderer(device, s)
+        c, _ = r.render()
+        r.close()
+        assert tuple(c[px[1], px[0]]) == expect
+        run_both(device, s)
