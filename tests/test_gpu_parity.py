@@ -269,7 +269,9 @@ def test_hierarchical_z_exact_ties_and_occlusion(device, depth_test, program):
 
 def test_hand_derived_kat_scenes_on_the_gpu(device):
     """The hand-derived known answers of tests/test_oracle_kat.py hold for the HIP path too (exact constants, no oracle)."""
-    from test_oracle_kat import _cfg1_dust2
+    from test_oracle_kat import _cfg1_dust2, near_clip_kat_scene
+    _, st = run_both(device, near_clip_kat_scene())
+    assert st["fragments_written"] == 8385 + 12481 and st["triangles_clipped"] == 1
     for args, px, expect in (((0.0, 1.0, 0.0), (128, 128), (0.25, 0.25, 0.5, 1.0)),
                              ((0.0, 2.0, 1.0), (128, 128), (0.625, 0.375, 0.375, 1.0)),
                              ((0.0, 0.5, 1.0), (128, 128), (1.0, 0.5, 0.25, 1.0))):

@@ -344,3 +344,43 @@ def test_cull_mode_front_is_negative_screen_area(oracle_lib):
     o = ob.OracleRenderer(256, 256)
     o.render_scene(s)
     assert o.stats()["fragments_written"] == 0
+
+
+def near_clip_kat_scene():
+    """One vertex behind the camera plane (W = -1), NearClip = 0, projection x'=x, y'=y, z'=z, w'=z+0.5.
+    ClipTriangleAgainstNearPlane (Rasterizer.cs:95-160) keeps v0, v1 (z' = 0.5 >= 0) and cuts the two edges at
+    t = 0.25 and t = 0.75 (exact), giving the polygon v0, v1, I1 = lerp(v1, v2, 1/4), I2 = lerp(v2, v0, 3/4) with
+    screen positions (64,192) (192,192) (192,64) (0,64); the fan is (v0,v1,I1), (v0,I1,I2).  (The first draft of this
+    test expected the flat colour everywhere; the oracle was right and the expectation wrong -- see the test body.)"""
+    P = np.eye(4, dtype=np.float32)
+    P[2, 3] = 1.0          # M34: w' += z
+    P[3, 3] = 0.5          # M44
+    pos = [(-0.5, -0.5, 0.5), (0.5, -0.5, 0.5), (-0.5, 2.5, -1.5)]
+    v = scenes.make_vertices(pos, color=[(0.5, 0.25, 1.0, 1.0)] * 3)
+    I = hm.identity()
+    d = scenes.Draw(v, np.array([0, 1, 2], dtype=np.uint16), I, I, P, program=Program.FlatColor,
+                    cull=CullMode.None_, depth_test=DepthTest.Disabled, blend=BlendMode.Alpha)
+    return scenes.Scene("near_clip_kat", 256, 256, [d], clear_color=(0.0, 0.0, 0.0, 1.0), near_clip=0.0)
+
+
+def test_near_plane_clip_polygon_and_fan(oracle_lib):
+    s = near_clip_kat_scene()
+    o = ob.OracleRenderer(256, 256)
+    color, _ = o.render_scene(s)
+    st = o.stats()
+    assert st["triangles_in"] == 1 and st["triangles_clipped"] == 1 and st["triangles_setup"] == 2
+    y, x = np.mgrid[0:256, 0:256]
+    t1 = (y >= 64) & (y <= 192) & (x <= 192) & (x + y >= 256)                 # (64,192) (192,192) (192,64)
+    t2 = (y >= 64) & (y <= 192) & (2 * x >= y - 64) & (x + y <= 256)          # (64,192) (192,64) (0,64)
+    assert t1.sum() == 8385 and t2.sum() == 12481 and (t1 & t2).sum() == 129  # the fan's inner edge is covered twice
+    assert st["fragments_tested"] == st["fragments_written"] == 8385 + 12481
+    covered = t1 | t2
+    assert np.array_equal(color[~covered], np.tile(np.float32([0, 0, 0, 1]), ((~covered).sum(), 1)))
+    # The cut vertices come from Shaders.Lerp(current, next, t, true) (Rasterizer.cs:142): Interpolate = TRUE even under
+    # a flat program, and outputs[0] of both fan triangles is such a vertex, so every fragment goes through the
+    # perspective interpolation: colour = c * fl(invSum * fl(1 / invSum)), i.e. c or a float neighbour of it ...
+    c = np.float32([0.5, 0.25, 1.0, 1.0])
+    got = color[covered].astype(np.float64) / c
+    # ... and alpha = 1 - 2^-24 at those fragments, so the Alpha blend scales the colour once more: never exactly flat
+    assert np.all(np.abs(got - 1.0) <= 2.0 ** -22)
+    assert (got != 1.0).any()
