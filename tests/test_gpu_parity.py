@@ -125,7 +125,8 @@ def test_no_clear_accumulates(device):
     lambda: scenes.state_scene(blend=BlendMode.Additive, depth_test=DepthTest.Always, seed=63),
     lambda: scenes.cfg3(256, 256, (2, 2), (12, 8), tex_size=64, seed=64),
     lambda: scenes.degenerate_scene(),
-], ids=["gouraud", "nearclip", "blend_none", "additive_always", "textured_patches", "degenerate"])
+    lambda: __import__("test_oracle_kat").wireframe_kat_scene(),
+], ids=["gouraud", "nearclip", "blend_none", "additive_always", "textured_patches", "degenerate", "hand_derived_kat"])
 def test_wireframe_debug_mode(device, make):
     """DebugMode.Wireframe = three DrawLine calls per triangle (Rasterizer.cs:232-340,419-425), incl. its quirks:
     every edge uses depths[0..1] / outputs[0..1] of the triangle, alpha test is `!= 0`, no row early-out."""
@@ -148,6 +149,8 @@ def test_wireframe_debug_mode(device, make):
     for k in ("triangles_in", "triangles_setup", "triangles_clipped", "fragments_tested", "fragments_shaded", "fragments_written"):
         assert st[k] == rst[k], (k, st[k], rst[k])
     assert rst["fragments_written"] > 0 or scene.name == "degenerate"
+    if scene.name == "wireframe_kat":
+        assert st["fragments_written"] == 3 * 128           # tests/test_oracle_kat.py::test_wireframe_drawline_by_hand
 
 
 def _random_scene(seed):

@@ -384,3 +384,32 @@ def test_near_plane_clip_polygon_and_fan(oracle_lib):
     # ... and alpha = 1 - 2^-24 at those fragments, so the Alpha blend scales the colour once more: never exactly flat
     assert np.all(np.abs(got - 1.0) <= 2.0 ** -22)
     assert (got != 1.0).any()
+
+
+def wireframe_kat_scene():
+    """Right triangle with screen vertices (64,64) (192,64) (64,192) for DebugMode.Wireframe."""
+    pos = [(-0.5, 0.5, 0.0), (0.5, 0.5, 0.0), (-0.5, -0.5, 0.0)]
+    v = scenes.make_vertices(pos, color=[(0.5, 0.25, 1.0, 1.0)] * 3)
+    I = hm.identity()
+    d = scenes.Draw(v, np.array([0, 1, 2], dtype=np.uint16), I, I, I, program=Program.FlatColor,
+                    cull=CullMode.None_, depth_test=DepthTest.Disabled, blend=BlendMode.Alpha)
+    return scenes.Scene("wireframe_kat", 256, 256, [d], clear_color=(0.0, 0.0, 0.0, 1.0))
+
+
+def test_wireframe_drawline_by_hand(oracle_lib):
+    """DrawLine (Rasterizer.cs:232-340): bbox from TRUNCATED endpoints, a pixel is drawn when its centre (x+.5, y+.5)
+    is within 0.5 of the segment.  Horizontal edge y = 64: the bbox holds row 64 only (centre 64.5, distance 0.5: in),
+    x = 64..191 (at x = 192 the clamped closest point is the end point, distance^2 = 0.5: out): 128 pixels; the
+    vertical edge likewise; the diagonal x + y = 256: centres with x + y + 1 = 256, i.e. x + y = 255 (distance^2 = 0.125;
+    the neighbours are at 0.5: out): 128 pixels.  The three corner pixels (64,64), (191,64), (64,191) lie on two edges."""
+    s = wireframe_kat_scene()
+    o = ob.OracleRenderer(256, 256)
+    color, _ = o.render_scene(s, debug_mode=1)
+    st = o.stats()
+    assert st["fragments_tested"] == st["fragments_written"] == 3 * 128
+    y, x = np.mgrid[0:256, 0:256]
+    rng = (x >= 64) & (x <= 191) & (y >= 64) & (y <= 191)
+    expect = rng & ((y == 64) | (x == 64) | (x + y == 255))
+    assert expect.sum() == 3 * 128 - 3
+    assert np.array_equal(color[expect], np.tile(np.float32([0.5, 0.25, 1.0, 1.0]), (expect.sum(), 1)))
+    assert np.array_equal(color[~expect], np.tile(np.float32([0, 0, 0, 1]), ((~expect).sum(), 1)))
