@@ -239,7 +239,8 @@ struct __attribute__((aligned(16))) WaveLdsC {
     uint32_t wpre[SWR_BATCH][4];     // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
     uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (pre[t] - 1) set for every pair t >= 1: pair of fragment g = #bits below g
     uint32_t pre[SWR_BATCH + 4];     // exclusive prefix of covered counts
-    uint32_t touched[8];             // chunk duplicate election: pixels already claimed in this chunk
+    uint32_t touched[64];            // chunk duplicate election: pixel p claimed <=> bit (p >> 6) of word (p & 63) -- neighbouring
+                                     // pixels (the usual content of a chunk) fall into different words: no same-address atomics
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -505,10 +506,10 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             // sharing a pixel loses does not matter: the chunk is cut at the LOWEST loser, so no two lanes before the
             // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
-            if (lane < 8) L.touched[lane] = (lane == (pix_first >> 5)) ? (1u << (pix_first & 31)) : 0u;
-            const uint32_t pbit = 1u << (pix & 31);
+            L.touched[lane] = (lane == (pix_first & 63)) ? (1u << (pix_first >> 6)) : 0u;
+            const uint32_t pbit = 1u << (pix >> 6);
             bool dup = false;
-            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix >> 5], pbit) & pbit) != 0u;
+            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix & 63], pbit) & pbit) != 0u;
             const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
