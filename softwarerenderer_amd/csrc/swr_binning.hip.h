@@ -471,20 +471,33 @@ __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ 
     if (n < 2) return;
     uint32_t* seg = tile_list + tile_start[tile];
 
-    if (n <= 64) {                                   // in registers, cross-lane shuffles
+    if (n <= 64) {
+        // In registers.  Partners inside a row of 16 lanes are reached on the DPP path (no LDS round trip): quad_perm for
+        // distances 1, 2 and the flip of 4, row_half_mirror / row_mirror for the flips of 8 / 16, row_ror for the xor
+        // of 4 / 8; only the three steps that cross rows (flips of 32 and 64, xor 16) go through ds_bpermute.
         uint32_t key = lane < n ? seg[lane] : 0xffffffffu;
-        for (uint32_t k = 2; k <= 64; k <<= 1) {
-            {   // flip step
-                uint32_t partner = lane ^ (k - 1);
-                uint32_t other = (uint32_t)__shfl((int)key, (int)partner);
-                key = (lane < partner) ? min(key, other) : max(key, other);
-            }
-            for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-                uint32_t partner = lane ^ j;
-                uint32_t other = (uint32_t)__shfl((int)key, (int)partner);
-                key = (lane < partner) ? min(key, other) : max(key, other);
-            }
-        }
+#define SWR_CMPX(other_expr, lower_cond) { const uint32_t other = (uint32_t)(other_expr); \
+                                            key = (lower_cond) ? min(key, other) : max(key, other); }
+#define SWR_DPP(ctrl) __builtin_amdgcn_update_dpp(0, (int)key, ctrl, 0xf, 0xf, false)
+#define SWR_XOR1  SWR_CMPX(SWR_DPP(0xB1), (lane & 1u) == 0u)                         /* quad_perm [1,0,3,2] */
+#define SWR_XOR2  SWR_CMPX(SWR_DPP(0x4E), (lane & 2u) == 0u)                         /* quad_perm [2,3,0,1] */
+#define SWR_XOR4  { const int up = SWR_DPP(0x124), dn = SWR_DPP(0x12C);              /* row_ror:4 = lane-4, row_ror:12 = lane+4 */ \
+                    SWR_CMPX((lane & 4u) ? up : dn, (lane & 4u) == 0u) }
+#define SWR_XOR8  SWR_CMPX(SWR_DPP(0x128), (lane & 8u) == 0u)                        /* row_ror:8 */
+#define SWR_XOR16 SWR_CMPX(__shfl((int)key, (int)(lane ^ 16u)), (lane & 16u) == 0u)
+        SWR_XOR1                                                                      // k = 2 (its flip is xor 1)
+        SWR_CMPX(SWR_DPP(0x1B), (lane & 2u) == 0u) SWR_XOR1                           // k = 4: flip = quad_perm [3,2,1,0]
+        SWR_CMPX(SWR_DPP(0x141), (lane & 4u) == 0u) SWR_XOR2 SWR_XOR1                 // k = 8: flip = row_half_mirror
+        SWR_CMPX(SWR_DPP(0x140), (lane & 8u) == 0u) SWR_XOR4 SWR_XOR2 SWR_XOR1        // k = 16: flip = row_mirror
+        SWR_CMPX(__shfl((int)key, (int)(lane ^ 31u)), (lane & 16u) == 0u) SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1              // k = 32
+        SWR_CMPX(__shfl((int)key, (int)(lane ^ 63u)), (lane & 32u) == 0u) SWR_XOR16 SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1    // k = 64
+#undef SWR_XOR16
+#undef SWR_XOR8
+#undef SWR_XOR4
+#undef SWR_XOR2
+#undef SWR_XOR1
+#undef SWR_DPP
+#undef SWR_CMPX
         if (lane < n) seg[lane] = key;
         return;
     }
