@@ -564,6 +564,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 if (!EARLYOUT) {
                     if (depth_func(f_dt, d, L.z[pix])) {                                                   // :505 / :318
                         ++n_shaded;
+                        const float4 dst = L.col[pix];        // read before the shading: off the dependent path of the blend
 #ifdef SWR_ABL_NOSHADE
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
@@ -572,7 +573,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
                         if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
-                            const float4 dst = L.col[pix];
                             L.col[pix] = blend(src, dst, f_blend);                                         // :513-515
                             if (f_dt != SWR_DEPTH_DISABLED) L.z[pix] = d;                                  // :517-518
                             ++n_written;
