@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -32,6 +33,8 @@ struct swr_mesh {
     uint16_t* d_idx = nullptr;
     int n_verts = 0, n_idx = 0;
     bool transient = false;
+    float box_lo[3] = { 0, 0, 0 }, box_hi[3] = { 0, 0, 0 };   // exact model-space AABB of the vertices (host, at creation)
+    bool has_box = false;
 };
 struct swr_texture {
     uint8_t* d_rgba = nullptr;
@@ -632,6 +635,43 @@ int ensure_bounds(swr_context* c, swr_mesh* m) {
     return SWR_OK;
 }
 
+// Multi-GPU bands: a mesh whose exact bounding box projects entirely above or below this context's band of tile
+// rows produces no fragment here, so the draw is not recorded at all (every rank would otherwise run the vertex, setup
+// and count stages for all triangles).  Conservative: double arithmetic, all eight corners must be in front of the
+// camera plane (w > 0: then every point of the box projects inside the hull of the projected corners), two pixels of
+// margin against the float32 roundings of the device transform and the floor / ceil of the pixel bbox.
+static bool band_rejects(const swr_context* c, const swr_mesh* m, const float* model, const float* view, const float* proj) {
+    if (!m->has_box || (c->band_ty0 <= 0 && c->band_ty1 >= c->tiles_y)) return false;
+    double mv[16], M[16];
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) {
+            double a = 0;
+            for (int j = 0; j < 4; ++j) a += (double)model[r * 4 + j] * (double)view[j * 4 + k];
+            mv[r * 4 + k] = a;
+        }
+    for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < 4; ++k) {
+            double a = 0;
+            for (int j = 0; j < 4; ++j) a += mv[r * 4 + j] * (double)proj[j * 4 + k];
+            M[r * 4 + k] = a;
+        }
+    double smin = 1e300, smax = -1e300;
+    for (int corner = 0; corner < 8; ++corner) {
+        const double x = (corner & 1) ? m->box_hi[0] : m->box_lo[0];
+        const double y = (corner & 2) ? m->box_hi[1] : m->box_lo[1];
+        const double z = (corner & 4) ? m->box_hi[2] : m->box_lo[2];
+        const double cy = x * M[1] + y * M[5] + z * M[9] + M[13];
+        const double cw = x * M[3] + y * M[7] + z * M[11] + M[15];
+        const double scale = std::fabs(x * M[3]) + std::fabs(y * M[7]) + std::fabs(z * M[11]) + std::fabs(M[15]);
+        if (!(cw > 1e-6 * scale) || !std::isfinite(cy) || !std::isfinite(cw)) return false;     // not safely in front: keep
+        const double sy = (1.0 - ((cy / cw) * 0.5 + 0.5)) * (double)c->H;                        // Rasterizer.cs:385-386
+        if (!std::isfinite(sy)) return false;
+        smin = std::min(smin, sy); smax = std::max(smax, sy);
+    }
+    const double y0 = (double)band_y0(c), y1 = (double)std::min(c->H, c->band_ty1 * SWR_TILE);   // band = pixel rows [y0, y1)
+    return smax < y0 - 2.0 || smin > y1 + 1.0;
+}
+
 int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
                 int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend, bool frustum_cull = false) {
     if (!mesh || !model || !view || !proj) return fail(c, SWR_ERR_INVALID_ARG, "null argument to render_mesh");
@@ -644,6 +684,7 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     if (c->W <= 0 || c->H <= 0) return SWR_OK;                      // Rasterizer.cs:176
     const int n_tris = mesh->n_idx / 3;                             // Rasterizer.cs:180
     if (n_tris == 0) return SWR_OK;
+    if (band_rejects(c, mesh, model, view, proj)) return SWR_OK;      // nothing of it can land in this band
     // keep a batch within the 32-bit slot / vertex numbering
     if (c->pend_tris + (uint64_t)n_tris > (1ull << 27) || c->pend_verts + (uint64_t)mesh->n_verts > (1ull << 28)) {
         int rc = flush_locked(c);
@@ -673,6 +714,17 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
         if ((int)idx[i] >= nv) return fail(c, SWR_ERR_INVALID_ARG, "index out of range (C#: IndexOutOfRangeException)");
     swr_mesh* m = new swr_mesh();
     m->n_verts = nv; m->n_idx = ni; m->transient = transient;
+    if (nv > 0) {                                  // exact AABB (min / max only): input to band_rejects
+        bool ok = true;
+        for (int k = 0; k < 3; ++k) { m->box_lo[k] = v[0].position[k]; m->box_hi[k] = v[0].position[k]; }
+        for (int i = 0; i < nv; ++i)
+            for (int k = 0; k < 3; ++k) {
+                const float p = v[i].position[k];
+                if (!(p == p)) ok = false;
+                m->box_lo[k] = std::min(m->box_lo[k], p); m->box_hi[k] = std::max(m->box_hi[k], p);
+            }
+        m->has_box = ok;
+    }
     hipError_t e = hipSuccess;
     if (nv) e = hipMalloc((void**)&m->d_verts, (size_t)nv * sizeof(swr_vertex));
     if (e == hipSuccess && ni) e = hipMalloc((void**)&m->d_idx, (size_t)ni * 2 + 8);
