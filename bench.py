@@ -237,7 +237,7 @@ def main():
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
             frame_bytes = (W * H if world == 1 else color_t[0].shape[0] * W) * 20.0
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_raster",
+                "bound": "hbm", "kernel": "k_raster_c",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 5),
