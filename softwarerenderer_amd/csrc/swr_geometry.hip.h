@@ -199,9 +199,14 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
         const uint16_t* __restrict__ ip = dp->idx + 3u * local;
         const uint32_t r0 = dp->vert_base + ip[0], r1 = dp->vert_base + ip[1], r2 = dp->vert_base + ip[2];
         SVert v[3];
-        load_vout(vout_ro + r0, v[0].v);
-        load_vout(vout_ro + r1, v[1].v);
-        load_vout(vout_ro + r2, v[2].v);
+        // only the clip positions are needed unless the triangle has to be clipped (then the varyings are fetched below)
+        {
+            const float4 c0 = reinterpret_cast<const float4*>(vout_ro + r0)[0], c1 = reinterpret_cast<const float4*>(vout_ro + r1)[0],
+                         c2 = reinterpret_cast<const float4*>(vout_ro + r2)[0];
+            v[0].v.clip[0] = c0.x; v[0].v.clip[1] = c0.y; v[0].v.clip[2] = c0.z; v[0].v.clip[3] = c0.w;
+            v[1].v.clip[0] = c1.x; v[1].v.clip[1] = c1.y; v[1].v.clip[2] = c1.z; v[1].v.clip[3] = c1.w;
+            v[2].v.clip[0] = c2.x; v[2].v.clip[1] = c2.y; v[2].v.clip[2] = c2.z; v[2].v.clip[3] = c2.w;
+        }
         const bool interp = dp->program != SWR_PROG_FLAT_COLOR;
         v[0].interp = v[1].interp = v[2].interp = interp;
 
@@ -209,6 +214,9 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
         if (!(b0 && b1 && b2)) {                                                                   // :212
             if (b0 || b1 || b2) {                                                                  // :217
                 n_clipped = 1;
+                load_vout(vout_ro + r0, v[0].v);
+                load_vout(vout_ro + r1, v[1].v);
+                load_vout(vout_ro + r2, v[2].v);
                 // ClipTriangleAgainstNearPlane, Rasterizer.cs:95-160
                 SVert poly[4];
                 int n = 0;
