@@ -66,7 +66,7 @@ EXPORTS = [
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
-    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters",
+    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters", "swr_selftest_division",
 ]
 
 _lib = None
@@ -130,6 +130,7 @@ def load() -> C.CDLL:
         "swr_profile_reset": (I, [P]),
         "swr_device_name": (I, [P, C.c_char_p, I]),
         "swr_debug_counters": (I, [P, C.POINTER(C.c_uint64)]),
+        "swr_selftest_division": (I, [P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -275,7 +276,7 @@ enum { MODE_SYNC = 0, MODE_ASYNC = 1 };
 const unsigned long long kMaxPairs = 1ull << 30;       // list entries per round (4 GiB of slot ids)
 
 size_t pair_capacity(const swr_context* c) {
-    return std::min(std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 2)),
+    return std::min(std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 8)),
                     c->d_pair_refs.cap / 16);
 }
 int ensure_pairs(swr_context* c, size_t n) {
@@ -284,7 +285,7 @@ int ensure_pairs(swr_context* c, size_t n) {
     if ((rc = ensure(c, c->d_pair_tile, n * 4))) return rc;
     if ((rc = ensure(c, c->d_masks, n * 32))) return rc;
     if ((rc = ensure(c, c->d_pair_refs, n * 16))) return rc;
-    return ensure(c, c->d_pcounts, n * 2 + 64);
+    return ensure(c, c->d_pcounts, n * 8 + 64);
 }
 
 int run_clear(swr_context* c, bool& cc, bool& cd, const float rgba_[4]) {
@@ -394,7 +395,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.tile_list = c->d_tile_list.as<uint32_t>();
         ca.pair_tile = c->d_pair_tile.as<uint32_t>();
         ca.masks = c->d_masks.as<uint4>();
-        ca.counts = c->d_pcounts.as<uint16_t>();
+        ca.info = c->d_pcounts.as<uint2>();
         ca.refs = c->d_pair_refs.as<uint4>();
         ca.n_pairs = d_total;
         ca.tile_work = tile_work;
@@ -439,7 +440,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         {
             const dim3 g((n_tiles + 511u) & ~511u), t(64);       // one wave per tile (grid in whole 8 x 64 XCD segments)
             const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
-            const uint16_t* pc = (const uint16_t*)c->d_pcounts.as<uint16_t>();
+            const uint2* pc = (const uint2*)c->d_pcounts.as<uint2>();
             bool phong = false, none = false, dust2_default = true, grows = true, phong_default = true, gouraud_default = true;
             for (auto& d : b.draws) {
                 gouraud_default = gouraud_default && d.p.program == SWR_PROG_GOURAUD &&
@@ -542,7 +543,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if (!vblocks.empty()) {
         ScopedSpan sp(c, ST_VERTEX);
         hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
-                           d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible);
+                           d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible,
+                           reinterpret_cast<float*>((char*)c->d_upload.p + offsetof(DrawParams, fog_r1)));
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -1224,6 +1226,22 @@ int swr_debug_counters(swr_context* c, uint64_t out[8]) {
     if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemsetAsync(c->d_total.as<unsigned long long>() + 8, 0, 64, c->stream));
     return SWR_OK;
+}
+
+int swr_selftest_division(swr_context* c, uint64_t samples, uint64_t seed, uint64_t out[8]) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = ensure(c, c->d_scratch, 64))) return rc;
+    SWR_HIP(c, hipMemsetAsync(c->d_scratch.p, 0, 64, c->stream));
+    const int iters = 1024;
+    const uint64_t per_block = 256ull * (uint64_t)iters;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((samples + per_block - 1) / per_block, 1u << 20);
+    if (blocks) hipLaunchKernelGGL(k_selftest_division, dim3(blocks), dim3(256), 0, c->stream, (unsigned long long)seed, iters,
+                                   c->d_scratch.as<unsigned long long>());
+    SWR_HIP(c, hipGetLastError());
+    SWR_HIP(c, hipMemcpyAsync(out, c->d_scratch.p, 64, hipMemcpyDeviceToHost, c->stream));
+    return sync_locked(c);
 }
 
 int swr_device_name(swr_context* c, char* buf, int buflen) {

@@ -19,7 +19,8 @@
 #define SWR_EPSILON 1e-6f                // Rasterizer.cs:52
 #define SWR_FLAG_INTERP 0x80000000u
 #define SWR_FLAG_LINE   0x40000000u      // record is one DrawLine edge of DebugMode.Wireframe: sx/sy[0..1] = p0, p1
-#define SWR_DRAW_MASK   0x3fffffffu
+#define SWR_FLAG_FASTDIV 0x20000000u     // k_raster_c staging only: the pair's three clip.W and its draw's fog range are in div_operand_safe()'s range
+#define SWR_DRAW_MASK   0x1fffffffu
 
 #define SWR_TB_INVALID 0xffffffffffffffffull     // slot_tb word of a slot with nothing to rasterise
 
@@ -63,6 +64,8 @@ struct DrawParams {
     uint32_t n_verts, n_tris;
     uint32_t vert_base;     // first VOut of this draw
     uint32_t tri_base;      // first global triangle number of this draw
+    float fog_r1;           // rcp_refined(u.fog_end - u.fog_start), or 0 when that range is outside div_operand_safe():
+    float pad_;             // written on the device by k_vertex (the fragment program's fog division, Renderer.cs:855)
 };
 
 struct Counters {           // device-side swr_stats accumulators
@@ -119,6 +122,54 @@ __device__ __forceinline__ float math_clamp(float v, float lo, float hi) {   // 
     if (v < lo) return lo;
     else if (v > hi) return hi;
     return v;
+}
+
+// ---------------------------------------------------------------- exact division / sqrt without the scaling steps ----
+// hipcc expands a correctly rounded f32 division n / d (the flag above) to
+//     d' = v_div_scale(d)   n' = v_div_scale(n)          (a power-of-two rescue for extreme exponents; vcc = "rescaled")
+//     r0 = v_rcp_f32(d')    e = fma(-d', r0, 1)    r1 = fma(e, r0, r0)
+//     q0 = n' * r1          e2 = fma(-d', q0, n')  q1 = fma(e2, r1, q0)    e3 = fma(-d', q1, n')
+//     q  = v_div_fmas(e3, r1, q1)   (= fma, times 2^+-64 if vcc)           result = v_div_fixup(q, d, n)   (NaN / Inf / 0 / denormal cases)
+// When |n| and |d| lie in [2^-40, 2^40] none of v_div_scale's rescue conditions holds (they need an exponent
+// difference >= 96, a denormal operand or quotient, or |n| < 2^-103), so d' = d, n' = n, vcc = 0, v_div_fmas is a
+// plain fma and v_div_fixup returns q: the division IS the eight-instruction core below.  r1 depends on d only, so a
+// denominator shared by many fragments (a vertex's clip.W, a draw's fog range) pays rcp_refined ONCE and each quotient
+// costs 1 mul + 4 fma instead of 11 instructions -- bit for bit the same quotient, because it is the same instruction
+// sequence on the same operands (fma used inside a correctly rounded division is not a contraction of reference
+// arithmetic).  swr_selftest_division compares it with the compiler's `/` over random, near-midpoint and boundary
+// operands on the GPU (tests/test_gpu_api.py::test_exact_division_core_matches_ieee_division).
+__device__ __forceinline__ float rcp_refined(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+__device__ __forceinline__ float div_core(float n, float d, float r1) {
+    const float q0 = n * r1;
+    const float e2 = __builtin_fmaf(-d, q0, n);
+    const float q1 = __builtin_fmaf(e2, r1, q0);
+    const float e3 = __builtin_fmaf(-d, q1, n);
+    return __builtin_fmaf(e3, r1, q1);
+}
+// |v| in [2^-40, 2^40], by its bit pattern (NaN, Inf, zero and denormals are all outside)
+#define SWR_DIV_LO_BITS 0x2B800000u      // 2^-40
+#define SWR_DIV_HI_BITS 0x53800000u      // 2^40
+__device__ __forceinline__ bool div_operand_safe(float v) {
+    return ((__float_as_uint(v) & 0x7fffffffu) - SWR_DIV_LO_BITS) <= (SWR_DIV_HI_BITS - SWR_DIV_LO_BITS);
+}
+__device__ __forceinline__ bool div_operands_safe3(float a, float b, float c) {
+    const uint32_t ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu, uc = __float_as_uint(c) & 0x7fffffffu;
+    return min(min(ua, ub), uc) >= SWR_DIV_LO_BITS && max(max(ua, ub), uc) <= SWR_DIV_HI_BITS;
+}
+// hipcc's correctly rounded sqrtf is: scale x by 2^32 if x < 2^-96; s = v_sqrt_f32(x); step s down one ulp if
+// fma(-(s-1ulp), s, x) <= 0, up one ulp if fma(-(s+1ulp), s, x) > 0; unscale; return x itself for +-0 / +inf.
+// For x in [2^-40, 2^40] the scaling and the class test are no-ops: the five-instruction core below is the same sqrt.
+__device__ __forceinline__ float sqrt_core(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    float r = rd <= 0.0f ? sd : s;
+    r = ru > 0.0f ? su : r;
+    return r;
 }
 
 // ---------------------------------------------------------------- System.Numerics ----

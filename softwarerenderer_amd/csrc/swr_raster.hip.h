@@ -47,7 +47,12 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
     // everything that does not need the texel first (its load is in flight, see shade_fragment)
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
-    float fog = math_clamp((u.fog_end - f.clip_z) / (u.fog_end - u.fog_start), 0.0f, 1.0f);
+    // (FogEnd - depth) / (FogEnd - FogStart), Renderer.cs:855: the denominator is per draw, its refined reciprocal was
+    // computed once by k_vertex (dp->fog_r1, 0 = out of the safe range) -- see div_core in swr_device.h
+    const float fog_num = u.fog_end - f.clip_z, fog_den = u.fog_end - u.fog_start;
+    float fog_q = div_core(fog_num, fog_den, dp->fog_r1);
+    if (!(dp->fog_r1 != 0.0f && div_operand_safe(fog_num))) fog_q = fog_num / fog_den;
+    float fog = math_clamp(fog_q, 0.0f, 1.0f);
     fog = (fog * fog) * (3.0f - 2.0f * fog);
     float s = 0.1f + 0.9f * diffuse;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -108,6 +113,8 @@ struct TriVaryings {
     float4 a_col, b_col, c_col;
     float4 a_uvn, b_uvn, c_uvn;
     float a_wnz, b_wnz, c_wnz;
+    float a_r1, b_r1, c_r1;                    // rcp_refined(clip.w) of each output (staged once per pair)
+    bool fastdiv;                              // the three clip.w are in div_operand_safe()'s range
     float a_wpos[3], b_wpos[3], c_wpos[3];     // PHONG only
 };
 
@@ -123,9 +130,16 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     const float4 a_uvn = V.a_uvn, b_uvn = V.b_uvn, c_uvn = V.c_uvn;
     if (simple && !interp) return a_col;                                                             // :622-627
 
-    float ra = w0f / a_clip.w;              // :576-578
-    float rb = w1f / b_clip.w;
-    float rc = w2f / c_clip.w;
+    // :576-578, true divisions: the denominators are per pair, so their refined reciprocals are staged and each quotient
+    // is the division's own mul + 4 fma core (div_core, swr_device.h); operands outside its range take the full sequence
+    float ra = div_core(w0f, a_clip.w, V.a_r1);
+    float rb = div_core(w1f, b_clip.w, V.b_r1);
+    float rc = div_core(w2f, c_clip.w, V.c_r1);
+    if (!(V.fastdiv && div_operands_safe3(w0f, w1f, w2f))) {
+        ra = w0f / a_clip.w;
+        rb = w1f / b_clip.w;
+        rc = w2f / c_clip.w;
+    }
     float inv_sum = (ra + rb) + rc;         // :579
     float w = 1.0f / inv_sum;               // :582
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
@@ -162,7 +176,8 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         float n2 = (V.a_wnz * wa + V.b_wnz * wb) + V.c_wnz * wc;
         float len_sq = dot3(n0, n1, n2, n0, n1, n2);
         if (len_sq > 1e-6f) {
-            float s = 1.0f / sqrtf(len_sq);
+            // 1 / MathF.Sqrt(lenSq): both correctly rounded; inside sqrt_core's range the square root needs no scaling
+            float s = 1.0f / (len_sq <= 1.0e12f ? sqrt_core(len_sq) : sqrtf(len_sq));
             n0 = n0 * s; n1 = n1 * s; n2 = n2 * s;
         }
         f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
@@ -224,6 +239,78 @@ __global__ __launch_bounds__(1024) void k_reduce_tile_stats(const uint32_t* __re
         for (int wv = 0; wv < 16; ++wv) sum += s[threadIdx.x][wv];
         out3[threadIdx.x] = sum;
     }
+}
+
+// ---- self-test of the exact division / sqrt cores (swr_device.h) against the compiler's own `/` and sqrtf ----
+// mode 0: random operands over the whole safe range; 1: quotients next to a rounding midpoint (n = d * (q + half ulp),
+// the hard cases of a final correction step); 2: exponents and significands at the guard's boundaries; 3: operands of
+// the shapes the raster kernel divides (edge weights in [-1, 0] by clip.w, fog ranges).  Sqrt: random, and x next to
+// s*s for random s (rounding boundaries of the square root).  out: [0] divisions tested, [1] division mismatches,
+// [2] sqrt tested, [3] sqrt mismatches, [4..7] first mismatching {n, d, got, want} bit patterns.
+__device__ __forceinline__ unsigned long long selftest_mix(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float selftest_operand(unsigned long long r, int emin_field, int emax_field) {
+    const uint32_t mant = (uint32_t)r & 0x7fffffu, sign = (uint32_t)(r >> 23) & 1u;
+    const uint32_t e = (uint32_t)emin_field + (uint32_t)((r >> 24) % (unsigned long long)(emax_field - emin_field + 1));
+    return __uint_as_float((sign << 31) | (e << 23) | mant);
+}
+__global__ __launch_bounds__(256) void k_selftest_division(unsigned long long seed, int iters, unsigned long long* __restrict__ out) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+    unsigned div_bad = 0, sqrt_bad = 0, div_n = 0, sqrt_n = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned long long r0 = selftest_mix(seed ^ (gid * 0x100000001B3ull + (unsigned long long)it));
+        const unsigned long long r1 = selftest_mix(r0), r2 = selftest_mix(r1);
+        const int mode = (int)(r2 >> 61) & 3;
+        float n, d;
+        if (mode == 0) {
+            n = selftest_operand(r0, 87, 166); d = selftest_operand(r1, 87, 166);
+        } else if (mode == 1) {
+            d = selftest_operand(r1, 120, 134);
+            const double q = 1.0 + (double)((uint32_t)r0 & 0x7fffffu) * (1.0 / 8388608.0) + (1.0 / 16777216.0);   // midpoint of two floats in [1, 2)
+            const int sh = (int)((r0 >> 32) % 41ull) - 20;
+            n = (float)(ldexp(q, sh) * (double)d);                       // nearest float to d * midpoint
+            if ((r0 >> 60) & 1ull) n = __uint_as_float(__float_as_uint(n) + (((r0 >> 61) & 1ull) ? 1u : 0xffffffffu));   // and its neighbours
+        } else if (mode == 2) {
+            const uint32_t efs[6] = { 87u, 88u, 127u, 165u, 166u, 126u };
+            const uint32_t mts[6] = { 0u, 1u, 0x7fffffu, 0x7ffffeu, 0x400000u, (uint32_t)r2 & 0x7fffffu };
+            n = __uint_as_float(((uint32_t)(r0 >> 40) & 1u) << 31 | efs[(r0 >> 8) % 6ull] << 23 | mts[(r0 >> 16) % 6ull]);
+            d = __uint_as_float(((uint32_t)(r1 >> 40) & 1u) << 31 | efs[(r1 >> 8) % 6ull] << 23 | mts[(r1 >> 16) % 6ull]);
+            if (((r2 >> 8) & 15ull) == 0ull) n = 1099511627776.0f;      // 2^40 itself, the top of the range
+            if (((r2 >> 12) & 15ull) == 0ull) d = -1099511627776.0f;
+        } else {
+            n = -(float)((uint32_t)r0 & 0xffffffu) * (1.0f / 16777216.0f) - 1.0e-7f;                       // an edge weight
+            d = 0.05f + (float)((uint32_t)r1 & 0xfffffu) * (2000.0f / 1048576.0f);                          // a clip.w
+            if ((r2 >> 20) & 1ull) { n = 25.0f - (float)((uint32_t)r0 & 0xffffffu) * (60.0f / 16777216.0f); d = 24.0f; }   // fog
+        }
+        if (div_operand_safe(n) && div_operand_safe(d)) {
+            const float got = div_core(n, d, rcp_refined(d));
+            const float want = n / d;
+            ++div_n;
+            if (__float_as_uint(got) != __float_as_uint(want)) {
+                if (atomicAdd(&out[1], 1ull) == 0ull) {
+                    out[4] = __float_as_uint(n); out[5] = __float_as_uint(d); out[6] = __float_as_uint(got); out[7] = __float_as_uint(want);
+                }
+                ++div_bad;
+            }
+        }
+        // square roots: a random operand, or the neighbourhood of a perfect square's rounding boundary
+        float x = fabsf(selftest_operand(r2, 87, 166));
+        if ((r1 >> 50) & 1ull) {
+            const float sroot = fabsf(selftest_operand(r0, 108, 146));
+            const float sq = sroot * sroot;
+            x = __uint_as_float(__float_as_uint(sq) + (uint32_t)((r1 >> 52) % 5ull) - 2u);
+        }
+        if (div_operand_safe(x)) {
+            const float got = sqrt_core(x), want = sqrtf(x);
+            ++sqrt_n;
+            if (__float_as_uint(got) != __float_as_uint(want)) { atomicAdd(&out[3], 1ull); ++sqrt_bad; }
+        }
+    }
+    (void)div_bad; (void)sqrt_bad;
+    atomicAdd(&out[0], (unsigned long long)div_n);
+    atomicAdd(&out[2], (unsigned long long)sqrt_n);
 }
 
 // Rasterizer.Interpolate (public API, Rasterizer.cs:566-640), batched: one thread per weight triple.

@@ -53,7 +53,8 @@ struct CoverArgs {
     const uint32_t* __restrict__ tile_list;   // sorted: slot id per pair
     const uint32_t* __restrict__ pair_tile;   // band-local tile index per pair
     uint4* __restrict__ masks;                // 2 x uint4 per pair: row r -> bits (r & 1) * 16 .. of word r >> 1
-    uint16_t* __restrict__ counts;            // popcount of the mask
+    uint2* __restrict__ info;                 // {popcount of the mask, hi-Z bound: an upper bound of the pair's fragment depths
+                                              //  over bbox /\ tile as float bits (+inf = no bound)}: one load in the raster kernel's window
     uint4* __restrict__ refs;                 // {slot, vertex references of outputs[0..2]}: the raster kernel's batch set-up
                                               // then needs no load that depends on another load
     const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
@@ -121,6 +122,35 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
         const int startY = max((int)(bby & 0xffffu), y0), endY = min((int)(bby >> 16), tile_end_y);
         const bool is_line = LINES && (__float_as_uint(r3.w) & SWR_FLAG_LINE) != 0u;
+        // Hierarchical-Z bound for the raster kernel (used there only under Less / LessEqual, where stored depth only
+        // grows): U >= every fragment depth of this pair.  Proof (u = 2^-24, R = bbox /\ tile, M_i as in
+        // pair_may_cover, S = sum |d_i invArea| M_i): every edge value of the reference's chain is within 35uM_i of the
+        // exact edge function (swr_binning.hip.h), so the fragment's float depth (two products, two sums) is within
+        // 39.3uS of the exact affine depth; that is maximal at a corner of R; the corners evaluated in float below are
+        // within 7.3uS; margin used: 64uS.  Lines and non-finite cases get +inf (never hidden).
+        float zbound = __uint_as_float(0x7f800000u);
+        if (!is_line && startX <= endX && startY <= endY) {
+            const float fxs = (float)startX, fxe = (float)endX, fys = (float)startY, fye = (float)endY;
+            const float sx[3] = { r0.x, r0.y, r0.z }, sy[3] = { r0.w, r1.x, r1.y };
+            const float dd[3] = { r1.z, r1.w, r2.x };
+            const float inv_area = r2.y;
+            // edge k (weight of depths[k]): a12,b12 about vertex 1; a20,b20 about vertex 2; a01,b01 about vertex 0
+            const float ea[3] = { sy[1] - sy[2], sy[2] - sy[0], sy[0] - sy[1] };
+            const float eb[3] = { sx[2] - sx[1], sx[0] - sx[2], sx[1] - sx[0] };
+            const float rx[3] = { sx[1], sx[2], sx[0] }, ry[3] = { sy[1], sy[2], sy[0] };
+            float c00 = 0.f, c10 = 0.f, c01 = 0.f, c11 = 0.f, S = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float kk = dd[k] * inv_area;
+                const float dxs = fxs - rx[k], dxe = fxe - rx[k], dys = fys - ry[k], dye = fye - ry[k];
+                const float xs = ea[k] * dxs, xe = ea[k] * dxe, ys = eb[k] * dys, ye = eb[k] * dye;
+                c00 += kk * (xs + ys); c10 += kk * (xe + ys); c01 += kk * (xs + ye); c11 += kk * (xe + ye);
+                S += fabsf(kk) * (fabsf(ea[k]) * fmaxf(fabsf(dxs), fabsf(dxe)) + fabsf(eb[k]) * fmaxf(fabsf(dys), fabsf(dye)));
+            }
+            const float U = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) + S * (64.0f / 16777216.0f);
+            const bool finite = S < 1.0e30f && c00 == c00 && c10 == c10 && c01 == c01 && c11 == c11;   // fmaxf drops NaNs
+            if (finite) zbound = U;
+        }
         if (is_line && startX <= endX && startY <= endY) {
             // DrawLine, Rasterizer.cs:292-313: every pixel of bbox /\ tile, centre within 0.5 px of the segment
             for (int y = startY; y <= endY; ++y) {
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         }
         a.masks[2 * (size_t)p] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
         a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
-        a.counts[p] = (uint16_t)cnt;
+        a.info[p] = make_uint2((uint32_t)cnt, __float_as_uint(zbound));
     }
     s_cnt[owner] = (uint16_t)cnt;
     __syncthreads();
@@ -262,7 +292,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
 __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
-                                                                  const uint16_t* __restrict__ counts) {
+                                                                  const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
     if (a.ctrl->poison) return;
 
@@ -287,12 +317,14 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
     const uint32_t start = a.tile_start[tile];
     WaveLdsC<PHONG>& L = s_w;
-    auto load_varyings = [&L](int t) {
+    auto load_varyings = [&L](int t, bool fastdiv) {
         TriVaryings V;
         V.a_clip = L.stage[4][t]; V.a_col = L.stage[5][t]; V.a_uvn = L.stage[6][t];
         V.b_clip = L.stage[7][t]; V.b_col = L.stage[8][t]; V.b_uvn = L.stage[9][t];
         V.c_clip = L.stage[10][t]; V.c_col = L.stage[11][t]; V.c_uvn = L.stage[12][t];
         V.a_wnz = V.a_clip.x; V.b_wnz = V.b_clip.x; V.c_wnz = V.c_clip.x;
+        V.a_r1 = V.a_clip.y; V.b_r1 = V.b_clip.y; V.c_r1 = V.c_clip.y;
+        V.fastdiv = fastdiv;
         if (PHONG) {
             const float4 a3 = L.stage[PHONG ? 13 : 0][t], b3 = L.stage[PHONG ? 14 : 0][t], c3 = L.stage[PHONG ? 15 : 0][t];
             V.a_wpos[0] = a3.y; V.a_wpos[1] = a3.z; V.a_wpos[2] = a3.w;
@@ -311,7 +343,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     // although a third of the candidates drops out.
     uint4 ref_w = make_uint4(0u, 0u, 0u, 0u);
     int cnt_w = 0;
-    if (lane < SWR_WINDOW && (uint32_t)lane < n) { ref_w = a.pair_refs[start + (uint32_t)lane]; cnt_w = (int)counts[start + (uint32_t)lane]; }
+    float zb_w = 0.0f;                     // hi-Z bound of the entry (k_cover)
+    if (lane < SWR_WINDOW && (uint32_t)lane < n) {
+        ref_w = a.pair_refs[start + (uint32_t)lane];
+        const uint2 pi = info[start + (uint32_t)lane];
+        cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
+    }
 
     // ---- tile init: clear fused, or one coalesced read of the framebuffer ----
 #pragma unroll
@@ -344,24 +381,13 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const uint4 ref = ref_w;
         const bool in_window = lane < SWR_WINDOW && base + (uint32_t)lane < n;
         const int cnt_in = in_window ? cnt_w : 0;
-        // one round trip: masks, TriRec and the three outputs of every non-empty pair
-        uint4 m0 = make_uint4(0u, 0u, 0u, 0u), m1 = m0;
-        float4 f0 = make_float4(0.f, 0.f, 0.f, 0.f), f1 = f0, f2 = f0, f3 = f0;
-        if (cnt_in > 0) {
-            m0 = masks[2 * (size_t)pidx]; m1 = masks[2 * (size_t)pidx + 1];
-            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
-            f0 = fq[0]; f1 = fq[1]; f2 = fq[2]; f3 = fq[3];
-        }
         int cnt = cnt_in;
         if (HIZ) {
             // Hierarchical Z.  Under Less / LessEqual the stored depth of a pixel only grows, so the minimum over the
             // tile at batch start bounds every later stored value from below.  A pair whose depth provably stays below
-            // it at every pixel of bbox /\ tile fails the depth test everywhere: the reference visits those fragments
-            // and writes nothing, so the pair is dropped here (its fragments still count as tested).
-            // Proof of the bound (u = 2^-24, R = bbox /\ tile, M_i as in pair_may_cover, S = sum |d_i invArea| M_i):
-            // every edge value of the reference's chain is within 35uM_i of the exact edge function (swr_binning.hip.h),
-            // so the fragment's float depth (two products, two sums) is within 39.3uS of the exact affine depth; that
-            // is maximal at a corner of R; the corners evaluated in float below are within 7.3uS; margin used: 64uS.
+            // it at every pixel of bbox /\ tile (k_cover's bound, see there) fails the depth test everywhere: the
+            // reference visits those fragments and writes nothing, so the pair is dropped here (its fragments still
+            // count as tested).  Exact ties are kept (strict <).
             float zmin = 3.0e38f;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -370,31 +396,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 zmin = fminf(zmin, inb ? L.z[p] : 3.0e38f);
             }
             zmin = wave_min(zmin);
-            if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE) {
-                const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
-                const float fxs = (float)max((int)(fbx & 0xffffu), x0), fxe = (float)min((int)(fbx >> 16), min(x0 + SWR_TILE - 1, W - 1));
-                const float fys = (float)max((int)(fby & 0xffffu), y0), fye = (float)min((int)(fby >> 16), min(y0 + SWR_TILE - 1, H - 1));
-                const float sx[3] = { f0.x, f0.y, f0.z }, sy[3] = { f0.w, f1.x, f1.y };
-                const float dd[3] = { f1.z, f1.w, f2.x };
-                const float inv_area = f2.y;
-                // edge k (weight of depths[k]): a12,b12 about vertex 1; a20,b20 about vertex 2; a01,b01 about vertex 0
-                const float ea[3] = { sy[1] - sy[2], sy[2] - sy[0], sy[0] - sy[1] };
-                const float eb[3] = { sx[2] - sx[1], sx[0] - sx[2], sx[1] - sx[0] };
-                const float rx[3] = { sx[1], sx[2], sx[0] }, ry[3] = { sy[1], sy[2], sy[0] };
-                float c00 = 0.f, c10 = 0.f, c01 = 0.f, c11 = 0.f, S = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float kk = dd[k] * inv_area;
-                    const float dxs = fxs - rx[k], dxe = fxe - rx[k], dys = fys - ry[k], dye = fye - ry[k];
-                    const float xs = ea[k] * dxs, xe = ea[k] * dxe, ys = eb[k] * dys, ye = eb[k] * dye;
-                    c00 += kk * (xs + ys); c10 += kk * (xe + ys); c01 += kk * (xs + ye); c11 += kk * (xe + ye);
-                    S += fabsf(kk) * (fabsf(ea[k]) * fmaxf(fabsf(dxs), fabsf(dxe)) + fabsf(eb[k]) * fmaxf(fabsf(dys), fabsf(dye)));
-                }
-                const float U = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) + S * (64.0f / 16777216.0f);
-                const bool finite = S < 1.0e30f && c00 == c00 && c10 == c10 && c01 == c01 && c11 == c11;   // fmaxf drops NaNs
-                const bool is_line = LINES && (__float_as_uint(f3.w) & SWR_FLAG_LINE) != 0u;
-                if (finite && !is_line && U < zmin) cnt = 0;
-            }
+            if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE && zb_w < zmin) cnt = 0;
         }
         // take the first SWR_BATCH survivors; the list is consumed up to and including the last one taken
         int consumed;
@@ -418,9 +420,14 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             r2.x = (uint32_t)__shfl((int)ref_w.x, src); r2.y = (uint32_t)__shfl((int)ref_w.y, src);
             r2.z = (uint32_t)__shfl((int)ref_w.z, src); r2.w = (uint32_t)__shfl((int)ref_w.w, src);
             const int c2 = __shfl(cnt_w, src);
-            ref_w = r2; cnt_w = c2;
+            const float z2 = __int_as_float(__shfl(__float_as_int(zb_w), src));
+            ref_w = r2; cnt_w = c2; zb_w = z2;
             const uint32_t e = base + (uint32_t)lane;
-            if (lane >= SWR_WINDOW - consumed && lane < SWR_WINDOW && e < n) { ref_w = a.pair_refs[start + e]; cnt_w = (int)counts[start + e]; }
+            if (lane >= SWR_WINDOW - consumed && lane < SWR_WINDOW && e < n) {
+                ref_w = a.pair_refs[start + e];
+                const uint2 pi = info[start + e];
+                cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
+            }
         }
         const int cincl = wave_incl_scan(cnt, lane);
         const int total = __builtin_amdgcn_readlane(cincl, 63);
@@ -429,12 +436,19 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
         if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
+            // one round trip: masks, TriRec and the three outputs of every surviving pair
+            const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
+            const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
+            const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
             const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
             const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + ref.z);
             const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + ref.w);
             const float4 a3 = pa[3], b3 = pb[3], c3 = pc[3];
             float4 a0 = pa[0], b0 = pb[0], c0 = pc[0];
             a0.x = a3.x; b0.x = b3.x; c0.x = c3.x;                           // clip.x is not read by fragments: wn.z rides there
+            // ... nor is clip.y: the refined reciprocal of clip.w rides there (Interpolate's divisions, see div_core)
+            const bool fastdiv = div_operands_safe3(a0.w, b0.w, c0.w);
+            a0.y = rcp_refined(a0.w); b0.y = rcp_refined(b0.w); c0.y = rcp_refined(c0.w);
             L.stage[4][ci] = a0; L.stage[5][ci] = pa[1]; L.stage[6][ci] = pa[2];
             L.stage[7][ci] = b0; L.stage[8][ci] = pb[1]; L.stage[9][ci] = pb[2];
             L.stage[10][ci] = c0; L.stage[11][ci] = pc[1]; L.stage[12][ci] = pc[2];
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     r0.w = f2.y;
                 }
                 L.stage[0][ci] = r0;
-                L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, f3.w);
+                L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, __uint_as_float(__float_as_uint(f3.w) | (fastdiv ? SWR_FLAG_FASTDIV : 0u)));
                 L.stage[2][ci] = make_float4(a12, a20, a01, __uint_as_float(fs));
                 L.stage[3][ci] = make_float4(b12, b20, b01, 0.0f);
             }
@@ -569,7 +583,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
                         const float4 src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
-                                                                 load_varyings(t), w0f, w1f, w2f);   // :507-509 / :321-323
+                                                                 load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
                         if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
@@ -583,7 +597,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
                         e_src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
-                                                      load_varyings(t), w0f, w1f, w2f);
+                                                      load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }
                 }

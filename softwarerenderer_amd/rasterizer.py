@@ -153,6 +153,13 @@ class Device:
     def profile_reset(self):
         self._ck(self._lib.swr_profile_reset(self._ctx))
 
+    def selftest_division(self, samples: int = 1 << 30, seed: int = 1) -> dict:
+        """swr_selftest_division: the kernels' exact-division / sqrt cores against the compiler's IEEE `/` and sqrtf."""
+        out = (C.c_uint64 * 8)()
+        self._ck(self._lib.swr_selftest_division(self._ctx, C.c_uint64(samples), C.c_uint64(seed), out))
+        keys = ("divisions", "division_mismatches", "sqrts", "sqrt_mismatches", "bad_n_bits", "bad_d_bits", "bad_got_bits", "bad_want_bits")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.swr_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
@@ -243,15 +250,31 @@ class MainWindow:
         self.RenderWidth = 0
         self.RenderHeight = 0
         self._band = None
+        self._bound = None
         self.Resize(render_width, render_height)
 
+    def _activate(self):
+        """A context owns ONE framebuffer (one MainWindow in the reference).  Several MainWindow objects on one Device
+        take turns: the one being used re-applies its geometry first; its previous pixels are then undefined."""
+        if getattr(self._dev, "_active_window", None) is self:
+            return
+        lib, ctx = self._dev._lib, self._dev._ctx
+        self._dev._ck(lib.swr_resize(ctx, self.RenderWidth, self.RenderHeight))
+        b = self._band if self._band is not None else (-1, -1)
+        self._dev._ck(lib.swr_set_band(ctx, b[0], b[1]))
+        cb = self._bound if self._bound is not None else (None, None)
+        self._dev._ck(lib.swr_bind_framebuffer(ctx, C.c_void_p(cb[0]) if cb[0] else None, C.c_void_p(cb[1]) if cb[1] else None))
+        self._dev._active_window = self
+
     def Resize(self, width: int, height: int):          # HandleResize, MainWindow.cs:320-321
-        self._dev._ck(self._dev._lib.swr_resize(self._dev._ctx, int(width), int(height)))
         self.RenderWidth, self.RenderHeight = int(width), int(height)
+        self._dev._active_window = None
+        self._activate()
 
     def SetBand(self, first_tile_row: int, n_tile_rows: int):
-        self._dev._ck(self._dev._lib.swr_set_band(self._dev._ctx, int(first_tile_row), int(n_tile_rows)))
-        self._band = (int(first_tile_row), int(n_tile_rows))
+        self._band = (int(first_tile_row), int(n_tile_rows)) if first_tile_row >= 0 and n_tile_rows >= 0 else None
+        self._dev._active_window = None
+        self._activate()
 
     def band_pixel_rows(self):
         tiles_y = (self.RenderHeight + 15) // 16
@@ -263,16 +286,21 @@ class MainWindow:
         return y0, max(0, y1 - y0)
 
     def BindFramebuffer(self, color_ptr: int, depth_ptr: int):
-        self._dev._ck(self._dev._lib.swr_bind_framebuffer(self._dev._ctx, C.c_void_p(color_ptr), C.c_void_p(depth_ptr)))
+        self._bound = (int(color_ptr), int(depth_ptr)) if color_ptr and depth_ptr else None
+        self._dev._active_window = None
+        self._activate()
 
     def ClearColorBuffer(self, clear_color):             # MainWindow.cs:400-407
+        self._activate()
         c = _f32(clear_color, 4)
         self._dev._ck(self._dev._lib.swr_clear_color(self._dev._ctx, _fptr(c)))
 
     def ClearDepthBuffer(self):                          # MainWindow.cs:429-436
+        self._activate()
         self._dev._ck(self._dev._lib.swr_clear_depth(self._dev._ctx))
 
     def _read(self, want_color=True, want_depth=True):
+        self._activate()
         _, rows = self.band_pixel_rows()
         w = max(self.RenderWidth, 0)
         col = np.empty((rows, w, 4), dtype=np.float32) if want_color else None
@@ -299,35 +327,42 @@ class MainWindow:
             out = np.empty(shape, dtype=np.float32)
         elif out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
             raise ValueError(f"out must be a C-contiguous float32 array of shape {shape}")
+        self._activate()
         if out.size:
             self._dev._ck(self._dev._lib.swr_readback_rgb(self._dev._ctx, out.ctypes.data))
         return out
 
     def FlattenTo(self, device_ptr: int):
         """FlatColorBuffer into caller-owned DEVICE memory (band rows x W x 3 floats); completes with Device.sync()."""
+        self._activate()
         self._dev._ck(self._dev._lib.swr_flatten_rgb_device(self._dev._ctx, C.c_void_p(device_ptr)))
 
     def Upload(self, color=None, depth=None):
+        self._activate()
         c = np.ascontiguousarray(color, dtype=np.float32) if color is not None else None
         d = np.ascontiguousarray(depth, dtype=np.float32) if depth is not None else None
         self._dev._ck(self._dev._lib.swr_upload(self._dev._ctx, c.ctypes.data if c is not None else None,
                                                 d.ctypes.data if d is not None else None))
 
     def GetPixel(self, x: int, y: int) -> np.ndarray:    # MainWindow.cs:391-398
+        self._activate()
         out = np.zeros(4, dtype=np.float32)
         self._dev._ck(self._dev._lib.swr_get_pixel(self._dev._ctx, int(x), int(y), _fptr(out)))
         return out
 
     def SetPixel(self, x: int, y: int, color):           # MainWindow.cs:382-388
+        self._activate()
         c = _f32(color, 4)
         self._dev._ck(self._dev._lib.swr_set_pixel(self._dev._ctx, int(x), int(y), _fptr(c)))
 
     def GetDepth(self, x: int, y: int) -> float:         # MainWindow.cs:420-426
+        self._activate()
         out = C.c_float(0.0)
         self._dev._ck(self._dev._lib.swr_get_depth(self._dev._ctx, int(x), int(y), C.byref(out)))
         return float(np.float32(out.value))
 
     def SetDepth(self, x: int, y: int, depth: float):    # MainWindow.cs:411-417
+        self._activate()
         self._dev._ck(self._dev._lib.swr_set_depth(self._dev._ctx, int(x), int(y), float(depth)))
 
 
@@ -414,6 +449,7 @@ class Rasterizer:
         prog = fragmentShader.program
         if vertexShader.program is not prog:
             raise ValueError("vertexShader and fragmentShader must come from the same ShaderProgram")
+        window._activate()
         dev = window._dev
         dev._ck(dev._lib.swr_set_state(dev._ctx, float(cls.NearClip), float(cls.FarClip), int(cls.RenderDebugMode)))
         m, v, p = _f32(model, 16), _f32(view, 16), _f32(projection, 16)

@@ -332,6 +332,7 @@ class SceneRenderer:
     def submit_frame(self):
         """One frame = RenderScene of Renderer.cs:404-419: clears, then one RenderMesh per mesh (not flushed)."""
         s, w = self.scene, self.window
+        w._activate()
         Rasterizer.NearClip, Rasterizer.FarClip = s.near_clip, s.far_clip
         if s.clear_depth:
             w.ClearDepthBuffer()

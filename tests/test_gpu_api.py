@@ -355,3 +355,17 @@ def test_pinned_host_buffer_readback(device):
     with pytest.raises(ValueError):
         r.window.FlatColorBuffer(out=np.zeros((3, 3, 3), dtype=np.float32))
     r.close()
+
+
+def test_exact_division_core_matches_ieee_division(device):
+    """The raster kernel divides by per-pair / per-draw denominators through the division's own mul + 4 fma core on a
+    staged refined reciprocal (csrc/swr_device.h).  2^31 operand pairs -- random over the guarded range, quotients next to
+    rounding midpoints, guard-boundary exponents / significands, renderer-shaped values -- must give the compiler's
+    correctly rounded quotient bit for bit; likewise the unscaled sqrt core."""
+    total = {"divisions": 0, "sqrts": 0}
+    for seed in (1, 2):
+        r = device.selftest_division(1 << 30, seed)
+        assert r["division_mismatches"] == 0, f"n={r['bad_n_bits']:#010x} d={r['bad_d_bits']:#010x} got={r['bad_got_bits']:#010x} want={r['bad_want_bits']:#010x}"
+        assert r["sqrt_mismatches"] == 0
+        total["divisions"] += r["divisions"]; total["sqrts"] += r["sqrts"]
+    assert total["divisions"] > 2_000_000_000 and total["sqrts"] > 2_000_000_000
