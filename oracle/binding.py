@@ -27,7 +27,7 @@ class OVertexOutput(C.Structure):     # oswr_vertex_output
 
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    so = os.path.join(_HERE, "liboswr.so")
+    so = os.path.join(_HERE, "liboswr_dpps.so")          # the last target of the Makefile's `all`
     src = os.path.join(_HERE, "swr_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
@@ -36,8 +36,12 @@ def build(force: bool = False) -> None:
 _libs = {}
 
 
-def load(fma: bool = False) -> C.CDLL:
-    name = "liboswr_fma.so" if fma else "liboswr.so"
+VARIANTS = {"": "liboswr.so", "fma": "liboswr_fma.so", "dotpw": "liboswr_dotpw.so", "fma_dotpw": "liboswr_fma_dotpw.so",
+            "dpps": "liboswr_dpps.so"}      # System.Numerics sensitivity builds (oracle/Makefile)
+
+
+def load(fma: bool = False, variant: str = None) -> C.CDLL:
+    name = VARIANTS[variant] if variant is not None else ("liboswr_fma.so" if fma else "liboswr.so")
     if name in _libs:
         return _libs[name]
     path = os.path.join(_HERE, name)
@@ -71,6 +75,7 @@ def load(fma: bool = False) -> C.CDLL:
     lib.oswr_depth_func.restype = I; lib.oswr_depth_func.argtypes = [I, F, F]
     lib.oswr_edge_function.restype = F; lib.oswr_edge_function.argtypes = [P, P, P]
     lib.oswr_numerics_fma.restype = I; lib.oswr_numerics_fma.argtypes = []
+    lib.oswr_dot_pairwise.restype = I; lib.oswr_dot_pairwise.argtypes = []
     lib.oswr_bounding_sphere.restype = None; lib.oswr_bounding_sphere.argtypes = [P, I, P]
     lib.oswr_is_sphere_in_frustum.restype = I; lib.oswr_is_sphere_in_frustum.argtypes = [P, P, P, P]
     _libs[name] = lib
@@ -84,8 +89,8 @@ def _f32(a):
 class OracleRenderer:
     """Renders a softwarerenderer_amd.scenes.Scene (or its draws one by one) on the CPU oracle."""
 
-    def __init__(self, width: int, height: int, threads: int = 1, fma: bool = False):
-        self.lib = load(fma)
+    def __init__(self, width: int, height: int, threads: int = 1, fma: bool = False, variant: str = None):
+        self.lib = load(fma, variant)
         self.ctx = self.lib.oswr_create(int(width), int(height))
         if not self.ctx:
             raise MemoryError("oswr_create failed")

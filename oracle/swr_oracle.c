@@ -104,8 +104,22 @@ static void vec3_transform_normal(const float n[3], const float m[16], float out
         out[j] = r;
     }
 }
+/* Vector3.Dot / LengthSquared on the (x, y, z, 0) lanes of a Vector128: the summation order is the second open
+ * System.Numerics ambiguity: 0 sequential, 1 dpps order, 2 two shuffle-adds (Vector128.Sum) */
+#ifndef SWR_DOT_PAIRWISE
+#define SWR_DOT_PAIRWISE 0
+#endif
+int oswr_dot_pairwise(void) { return SWR_DOT_PAIRWISE; }
 static inline float vec3_dot(const float a[3], const float b[3]) {
+#if SWR_DOT_PAIRWISE == 1
+    float p = a[0] * b[0] + a[1] * b[1], q = a[2] * b[2] + 0.0f;
+    return p + q;
+#elif SWR_DOT_PAIRWISE == 2
+    float p = a[0] * b[0] + a[2] * b[2], q = a[1] * b[1] + 0.0f;
+    return p + q;
+#else
     return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2];
+#endif
 }
 /* Vector3.Normalize(v) = v / v.Length() */
 static void vec3_normalize(const float v[3], float out[3]) {

@@ -18,7 +18,10 @@
  *   Vector3.Normalize(v)    = v / sqrt((x*x + y*y) + z*z)
  *   VectorN.Lerp(a,b,t)     = a*(1-t) + b*t
  * unfused by default; build with -DSWR_NUMERICS_FMA=1 to model a fused
- * MultiplyAddEstimate in Transform/TransformNormal/Lerp.
+ * MultiplyAddEstimate in Transform/TransformNormal/Lerp, and with -DSWR_DOT_PAIRWISE=1|2
+ * to model the two SIMD summation orders of Vector3.Dot / LengthSquared
+ * ((xx + yy) + (zz + 0) as dpps sums, (xx + zz) + (yy + 0) as two shuffle-adds do).
+ * oracle/Makefile builds every combination the HIP side is tested in.
  */
 #ifndef SWR_ORACLE_H
 #define SWR_ORACLE_H
@@ -136,6 +139,7 @@ void  oswr_blend(const float src[4], const float dst[4], int mode, float out[4])
 int   oswr_depth_func(int test, float new_depth, float old_depth);
 float oswr_edge_function(const float a[2], const float b[2], const float c[2]);
 int   oswr_numerics_fma(void);
+int   oswr_dot_pairwise(void);   /* SWR_DOT_PAIRWISE of this build: 0 sequential, 1 dpps order, 2 two shuffle-adds */
 
 /* FrustumCuller.cs (row N3 of SURVEY.md section 8f) */
 /* CalculateBoundingSphere, FrustumCuller.cs:59-151, in the serial schedule of its Parallel.For loops (one partition:

@@ -11,7 +11,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswr_hip.so")
+# SWR_LIB selects another in-tree build of the SAME source (the numerics sensitivity builds libswr_hip_fma.so /
+# libswr_hip_dotpw.so of csrc/Makefile, or a test build); there is no non-HIP alternative to select
+LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("SWR_LIB", "") or "libswr_hip.so"))
 
 SWR_OK = 0
 SWR_ERR_INVALID_ARG = -1
@@ -69,19 +71,21 @@ EXPORTS = [
     "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters", "swr_selftest_division",
 ]
 
-_lib = None
+_libs = {}
 
 
-def load() -> C.CDLL:
-    """Load libswr_hip.so (built by __graft_entry__.build()).  Raises if it is absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(name: str = None) -> C.CDLL:
+    """Load libswr_hip.so (built by __graft_entry__.build()), or another in-tree build of the same source by file name
+    (the numerics sensitivity builds, the test build).  Raises if it is absent.  The libraries are linked -Bsymbolic, so
+    several builds can live in one process without binding to each other's kernels."""
+    path = LIB_PATH if not name else os.path.join(_HERE, os.path.basename(name))
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). softwarerenderer_amd has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
     P, I, F = C.c_void_p, C.c_int, C.c_float
     fp = C.POINTER(C.c_float)
     sig = {
@@ -136,11 +140,11 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[path] = lib
     return lib
 
 
-def check(ctx, rc: int) -> None:
+def check(ctx, rc: int, lib: C.CDLL = None) -> None:
     if rc != SWR_OK:
-        msg = load().swr_last_error(ctx)
+        msg = (lib or load()).swr_last_error(ctx)
         raise SwrError(rc, msg.decode() if msg else "")

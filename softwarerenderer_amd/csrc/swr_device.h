@@ -13,6 +13,10 @@
 #ifndef SWR_NUMERICS_FMA
 #define SWR_NUMERICS_FMA 0   // 1 models a fused MultiplyAddEstimate inside System.Numerics Transform/Lerp
 #endif
+#ifndef SWR_DOT_PAIRWISE
+#define SWR_DOT_PAIRWISE 0   // summation order of Vector3.Dot / LengthSquared (Renderer.cs:835,851, Rasterizer.cs:684) on the
+#endif                       // (x, y, z, 0) lanes of a Vector128: 0 sequential (xx + yy) + zz; 1 dpps order (xx + yy) + (zz + 0);
+                             // 2 two shuffle-adds (Vector128.Sum) (xx + zz) + (yy + 0)
 
 #define SWR_TILE 16                      // Rasterizer.cs:53 TileSize -- part of the numerical contract
 #define SWR_FLOAT_MINVALUE (-3.40282347e+38f)   // float.MinValue, MainWindow.cs:425,434
@@ -20,7 +24,9 @@
 #define SWR_FLAG_INTERP 0x80000000u
 #define SWR_FLAG_LINE   0x40000000u      // record is one DrawLine edge of DebugMode.Wireframe: sx/sy[0..1] = p0, p1
 #define SWR_FLAG_FASTDIV 0x20000000u     // k_raster_c staging only: the pair's three clip.W and its draw's fog range are in div_operand_safe()'s range
-#define SWR_DRAW_MASK   0x1fffffffu
+#define SWR_FLAG_SIMPLE 0x10000000u      // k_raster_c staging only: every row of the pair's coverage mask is one run of pixels (k_cover's SWR_INFO_SIMPLE)
+#define SWR_DRAW_MASK   0x0fffffffu
+#define SWR_INFO_SIMPLE 0x80000000u      // k_cover's info.x: count | SWR_INFO_SIMPLE
 
 #define SWR_TB_INVALID 0xffffffffffffffffull     // slot_tb word of a slot with nothing to rasterise
 
@@ -202,7 +208,15 @@ __device__ __forceinline__ void vec3_transform_normal(const float n[3], const fl
     }
 }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
+#if SWR_DOT_PAIRWISE == 1
+    const float p = ax * bx + ay * by, q = az * bz + 0.0f;
+    return p + q;
+#elif SWR_DOT_PAIRWISE == 2
+    const float p = ax * bx + az * bz, q = ay * by + 0.0f;
+    return p + q;
+#else
     return (ax * bx + ay * by) + az * bz;
+#endif
 }
 __device__ __forceinline__ float nm_lerp(float a, float b, float t) {   // a*(1-t) + b*t
 #if SWR_NUMERICS_FMA

@@ -36,7 +36,10 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31
     return v;
 }
-// minimum over the wave (same DPP ladder; the last lane ends up with the result)
+// minimum over the wave (same DPP ladder; the last lane ends up with the result).  v_min_f32 with a DPP source operand:
+// a lane whose source lane does not exist is not written (no bound_ctrl), i.e. keeps its value; s_nop 1 = the two wait
+// states a DPP read needs after a VALU write of the same register.  NaNs are dropped like fminf does.
+#ifdef SWR_NO_ASM_MIN
 __device__ __forceinline__ float wave_min(float x) {
     const int big = __float_as_int(3.0e38f);
     int v = __float_as_int(x);
@@ -47,6 +50,19 @@ __device__ __forceinline__ float wave_min(float x) {
 #undef SWR_MIN_STEP
     return __int_as_float(__builtin_amdgcn_readlane(v, 63));
 }
+#else
+__device__ __forceinline__ float wave_min(float x) {
+    asm("s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n"
+                 "v_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n s_nop 1"
+                 : "+v"(x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+#endif
 
 struct CoverArgs {
     const TriRec* __restrict__ recs;
@@ -212,14 +228,24 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
             }
         }
         uint32_t mw[8];
+#ifdef SWR_NO_SIMPLE_SELECT                    // test builds: every pair takes the raster kernel's general k-th-set-bit search
+        uint32_t not_run = 1u;
+#else
+        uint32_t not_run = 0u;                 // a row whose covered pixels are not ONE run leaves a bit here
+#endif
 #pragma unroll
         for (int i = 0; i < 8; ++i) {          // word i = rows 2i (low half) and 2i+1 (high half)
-            mw[i] = (uint32_t)mrow16[2 * i] | ((uint32_t)mrow16[2 * i + 1] << 16);
+            const uint32_t lo = mrow16[2 * i], hi = mrow16[2 * i + 1];
+            not_run |= (lo & (lo + (lo & (0u - lo)))) | (hi & (hi + (hi & (0u - hi))));
+            mw[i] = lo | (hi << 16);
             cnt += __popc(mw[i]);
         }
         a.masks[2 * (size_t)p] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
         a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
-        a.info[p] = make_uint2((uint32_t)cnt, __float_as_uint(zbound));
+        // (along a row every edge value is monotone -- it is stepped by a constant -- so "all >= 0" and "all <= 0" are
+        // intervals and a row is one run unless both are non-empty and apart: sliver triangles only.  The raster kernel
+        // selects the k-th pixel of a run arithmetically and searches bit by bit only in pairs without this flag.)
+        a.info[p] = make_uint2((uint32_t)cnt | (not_run == 0u ? SWR_INFO_SIMPLE : 0u), __float_as_uint(zbound));
     }
     s_cnt[owner] = (uint16_t)cnt;
     __syncthreads();
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (lane < SWR_WINDOW && (uint32_t)lane < n) {
         ref_w = a.pair_refs[start + (uint32_t)lane];
         const uint2 pi = info[start + (uint32_t)lane];
-        cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
+        cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);          // cnt_w keeps k_cover's SWR_INFO_SIMPLE bit (the sign)
     }
 
     // ---- tile init: clear fused, or one coalesced read of the framebuffer ----
@@ -380,7 +406,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const uint32_t pidx = start + base + (uint32_t)lane;
         const uint4 ref = ref_w;
         const bool in_window = lane < SWR_WINDOW && base + (uint32_t)lane < n;
-        const int cnt_in = in_window ? cnt_w : 0;
+        const bool simple_in = cnt_w < 0;                                // SWR_INFO_SIMPLE
+        const int cnt_in = in_window ? (cnt_w & 0x7fffffff) : 0;
         int cnt = cnt_in;
         if (HIZ) {
             // Hierarchical Z.  Under Less / LessEqual the stored depth of a pixel only grows, so the minimum over the
@@ -396,7 +423,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 zmin = fminf(zmin, inb ? L.z[p] : 3.0e38f);
             }
             zmin = wave_min(zmin);
+#ifndef SWR_ABL_NOHIZ
             if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE && zb_w < zmin) cnt = 0;
+#endif
         }
         // take the first SWR_BATCH survivors; the list is consumed up to and including the last one taken
         int consumed;
@@ -472,7 +501,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     r0.w = f2.y;
                 }
                 L.stage[0][ci] = r0;
-                L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, __uint_as_float(__float_as_uint(f3.w) | (fastdiv ? SWR_FLAG_FASTDIV : 0u)));
+                L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, __uint_as_float(__float_as_uint(f3.w) | (fastdiv ? SWR_FLAG_FASTDIV : 0u) |
+                                                                                 (simple_in ? SWR_FLAG_SIMPLE : 0u)));
                 L.stage[2][ci] = make_float4(a12, a20, a01, __uint_as_float(fs));
                 L.stage[3][ci] = make_float4(b12, b20, b01, 0.0f);
             }
@@ -514,8 +544,25 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 const uint32_t wsel = L.mask[t][wi];
                 const int kw = k - (int)reinterpret_cast<const uint16_t*>(&L.wpre[t][0])[wi];
                 const bool okk = valid && kw < __popc(wsel);         // always true for a valid fragment
-                pix = wi * 32 + kth_set_bit32(wsel, okk ? kw : 0);
+                // the word holds two rows; when each is one run (SWR_FLAG_SIMPLE, nearly always) the k-th covered pixel
+                // is first-pixel-of-the-run + k
+                const bool simple = (__float_as_uint(f1.w) & SWR_FLAG_SIMPLE) != 0u;
+                const uint32_t lo = wsel & 0xffffu;
+                const int c0 = __popc(lo);
+                const bool up = kw >= c0;
+                const uint32_t half = up ? (wsel >> 16) : lo;
+                int posw = (up ? 16 + (kw - c0) : kw) + (__ffs((int)half) - 1);
+                if (__ballot(okk && !simple) != 0ull) {
+                    if (!simple) posw = kth_set_bit32(wsel, okk ? kw : 0);
+                }
+                pix = (wi * 32 + posw) & 255;
+#ifdef SWR_ABL_NOSELECT2      // tools/ablate.py timing experiments only (wrong image by design)
+                pix = (wi * 32 + kw) & 255;
+#endif
             }
+#ifdef SWR_ABL_NOSELECT
+            pix = k & 255;
+#endif
             // duplicate election: a lane whose pixel was already claimed in this chunk must wait.  Which of two lanes
             // sharing a pixel loses does not matter: the chunk is cut at the LOWEST loser, so no two lanes before the
             // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
@@ -523,7 +570,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             L.touched[lane] = (lane == (pix_first & 63)) ? (1u << (pix_first >> 6)) : 0u;
             const uint32_t pbit = 1u << (pix >> 6);
             bool dup = false;
+#ifndef SWR_ABL_NOELECT
             if (valid && lane > 0) dup = (atomicOr(&L.touched[pix & 63], pbit) & pbit) != 0u;
+#endif
             const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);

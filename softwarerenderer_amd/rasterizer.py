@@ -98,8 +98,9 @@ def euler_to_direction(pitch_deg: float, yaw_deg: float, roll_deg: float):
 class Device:
     """One swr_context = one GPU (one process per GPU)."""
 
-    def __init__(self, device_id: int = 0):
-        self._lib = N.load()
+    def __init__(self, device_id: int = 0, lib: str = None):
+        """`lib`: file name of another in-tree build of the backend (e.g. "libswr_hip_fma.so"); default = the product library."""
+        self._lib = N.load(lib)
         self._ctx = C.c_void_p()
         rc = self._lib.swr_create(int(device_id), C.byref(self._ctx))
         if rc != N.SWR_OK:
@@ -118,7 +119,7 @@ class Device:
             pass
 
     def _ck(self, rc):
-        N.check(self._ctx, rc)
+        N.check(self._ctx, rc, self._lib)
 
     @property
     def name(self) -> str:
