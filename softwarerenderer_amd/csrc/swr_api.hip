@@ -106,6 +106,7 @@ struct swr_context {
     std::vector<Batch> inflight;              // launched optimistically, not yet validated
     uint32_t next_seq = 1;
     bool sync_flush = false;                  // SWR_SYNC_FLUSH=1: read the pair total back in every flush
+    uint32_t debug_fill_capacity = 0;         // SWR_DEBUG_FILL_CAPACITY=n: k_bin<FILL> of optimistic flushes sees a list of n entries (tests)
 
     DevBuf d_upload, d_vout, d_recs, d_slot_tb;   // d_upload = draws | vertex block map | triangle block map of the running batch
     FrameSlot slots[SWR_SLOTS];
@@ -262,6 +263,7 @@ void free_garbage(swr_context* c) {       // stream must be idle
 }
 
 int validate_locked(swr_context* c);
+int check_list_overflow(swr_context* c);
 
 int sync_locked(swr_context* c) {
     SWR_HIP(c, hipStreamSynchronize(c->stream));
@@ -319,6 +321,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
     ba.ctrl = c->d_ctrl.as<Ctrl>();
+    ba.seq = b.seq; ba.replayable = 0;
     ba.total = c->d_total.as<unsigned long long>();
     ba.want = c->d_want.as<uint8_t>();
     ba.tpw = 64u;
@@ -335,6 +338,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     uint32_t* tile_order = tile_work + n_tiles;
     uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
     BinArgs ba = make_bin_args(c, b, lo, hi);
+    ba.replayable = mode == MODE_ASYNC ? 1u : 0u;
     const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;          // = triangles
     ba.tpw = 64u;                                                            // aim for >= ~1000 waves
     while (ba.tpw > 4u && bin_threads < ba.tpw * 1024u) ba.tpw >>= 1;
@@ -379,7 +383,10 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     }
     {
         ScopedSpan sp(c, ST_BIN);
-        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);       // cursors were zeroed by k_scan_apply
+        BinArgs bf = ba;
+        // test hook: a FILL capacity below what COUNT was checked against forces the list-overflow path (bin_overflow)
+        if (mode == MODE_ASYNC && c->debug_fill_capacity) bf.list_capacity = std::min(bf.list_capacity, c->debug_fill_capacity);
+        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, bf);       // cursors were zeroed by k_scan_apply
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -494,6 +501,9 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+    // the per-tile scan (k_scan_sums / k_scan_apply) holds 1024 block sums of 1024 tiles each
+    if (n_tiles > (1u << 20))
+        return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^20 tiles in one band (a target beyond 16384 x 16384): render it in tile-row bands (swr_set_band)");
 
     const size_t off_vb = (nd * sizeof(DrawParams) + 255) & ~(size_t)255;
     const size_t off_tb = (off_vb + vblocks.size() * sizeof(BlockMap) + 255) & ~(size_t)255;
@@ -568,14 +578,24 @@ void retire_batch(swr_context* c, Batch& b) {
     b.draws.clear();
 }
 
+// Counters::overflow (mirrored in the pinned word host_poison[1]): a list position beyond the capacity in a batch that
+// could not poison itself (synchronous flush: the lists were sized from the COUNT pass, so COUNT and FILL disagreed).
+// The dropped pair cannot be recovered there: report it instead of returning a silently wrong image.
+int check_list_overflow(swr_context* c) {
+    if (!c->host_poison || !((volatile uint32_t*)c->host_poison)[1]) return SWR_OK;
+    c->host_poison[1] = 0;
+    return fail(c, SWR_ERR_HIP, "internal error: a (triangle, tile) pair did not fit its tile list and was dropped (Counters::overflow)");
+}
+
 // stream must be idle: looks at the control block, replays what did not fit, retires the in-flight batches
 int validate_locked(swr_context* c) {
-    if (c->inflight.empty()) return SWR_OK;
+    if (c->inflight.empty()) return check_list_overflow(c);
     int rc = SWR_OK;
-    if (*(volatile uint32_t*)c->host_poison) {          // set by k_scan_apply together with Ctrl::poison (stream is idle here)
+    if (*(volatile uint32_t*)c->host_poison) {          // set by k_scan_apply / bin_overflow together with Ctrl::poison (stream is idle here)
         Ctrl h;
         SWR_HIP(c, hipMemcpy(&h, c->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost));
         *c->host_poison = 0;
+        c->host_poison[1] = 0;                              // an overflow inside an optimistic batch is cured by the replay below
         Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison;
         SWR_HIP(c, hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice));
         std::vector<Batch> todo;
@@ -588,11 +608,12 @@ int validate_locked(swr_context* c) {
             retire_batch(c, b);
         }
         if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = SWR_ERR_HIP; } }
+        if (!rc) rc = check_list_overflow(c);
         return rc;
     }
     for (auto& b : c->inflight) retire_batch(c, b);
     c->inflight.clear();
-    return SWR_OK;
+    return check_list_overflow(c);
 }
 
 int flush_locked(swr_context* c) {
@@ -639,39 +660,54 @@ int ensure_bounds(swr_context* c, swr_mesh* m) {
 
 // Multi-GPU bands: a mesh whose exact bounding box projects entirely above or below this context's band of tile
 // rows produces no fragment here, so the draw is not recorded at all (every rank would otherwise run the vertex, setup
-// and count stages for all triangles).  Conservative: double arithmetic, all eight corners must be in front of the
-// camera plane (w > 0: then every point of the box projects inside the hull of the projected corners), two pixels of
-// margin against the float32 roundings of the device transform and the floor / ceil of the pixel bbox.
+// and count stages for all triangles).  Conservative: the corners are projected in double arithmetic and must all be in
+// front of the camera plane (w > 0: then every point of the box projects inside the hull of the projected corners); the
+// margin covers what the DEVICE's float32 evaluation of a vertex can differ from that: the three chained row-vector
+// products of k_vertex (Renderer.cs:832-834) round 4 products + 3 sums per component and stage, so
+// |fl(clip_k) - clip_k| <= 16 * 2^-24 * (|p| |model| |view| |proj|)_k (the running-error bound with absolute values,
+// maximal at a corner of the box), which moves the screen row by at most H/2 * (E_y + |ndc_y| E_w) / (w - E_w); plus
+// two pixels for the viewport arithmetic and the floor / ceil of the pixel bbox.  With large cancelling translations
+// that bound exceeds any fixed margin -- then the draw is simply kept.
 static bool band_rejects(const swr_context* c, const swr_mesh* m, const float* model, const float* view, const float* proj) {
     if (!m->has_box || (c->band_ty0 <= 0 && c->band_ty1 >= c->tiles_y)) return false;
-    double mv[16], M[16];
+    double mv[16], M[16], amv[16], A[16];
     for (int r = 0; r < 4; ++r)
         for (int k = 0; k < 4; ++k) {
-            double a = 0;
-            for (int j = 0; j < 4; ++j) a += (double)model[r * 4 + j] * (double)view[j * 4 + k];
-            mv[r * 4 + k] = a;
+            double a = 0, b = 0;
+            for (int j = 0; j < 4; ++j) { a += (double)model[r * 4 + j] * (double)view[j * 4 + k]; b += std::fabs((double)model[r * 4 + j]) * std::fabs((double)view[j * 4 + k]); }
+            mv[r * 4 + k] = a; amv[r * 4 + k] = b;
         }
     for (int r = 0; r < 4; ++r)
         for (int k = 0; k < 4; ++k) {
-            double a = 0;
-            for (int j = 0; j < 4; ++j) a += mv[r * 4 + j] * (double)proj[j * 4 + k];
-            M[r * 4 + k] = a;
+            double a = 0, b = 0;
+            for (int j = 0; j < 4; ++j) { a += mv[r * 4 + j] * (double)proj[j * 4 + k]; b += amv[r * 4 + j] * std::fabs((double)proj[j * 4 + k]); }
+            M[r * 4 + k] = a; A[r * 4 + k] = b;
         }
-    double smin = 1e300, smax = -1e300;
+    const double u16 = 16.0 / 16777216.0;
+    double smin = 1e300, smax = -1e300, ey = 0, ew = 0, wmin = 1e300, ndc_abs = 0;
     for (int corner = 0; corner < 8; ++corner) {
         const double x = (corner & 1) ? m->box_hi[0] : m->box_lo[0];
         const double y = (corner & 2) ? m->box_hi[1] : m->box_lo[1];
         const double z = (corner & 4) ? m->box_hi[2] : m->box_lo[2];
         const double cy = x * M[1] + y * M[5] + z * M[9] + M[13];
         const double cw = x * M[3] + y * M[7] + z * M[11] + M[15];
-        const double scale = std::fabs(x * M[3]) + std::fabs(y * M[7]) + std::fabs(z * M[11]) + std::fabs(M[15]);
-        if (!(cw > 1e-6 * scale) || !std::isfinite(cy) || !std::isfinite(cw)) return false;     // not safely in front: keep
-        const double sy = (1.0 - ((cy / cw) * 0.5 + 0.5)) * (double)c->H;                        // Rasterizer.cs:385-386
+        const double sy_abs = std::fabs(x) * A[1] + std::fabs(y) * A[5] + std::fabs(z) * A[9] + A[13];
+        const double sw_abs = std::fabs(x) * A[3] + std::fabs(y) * A[7] + std::fabs(z) * A[11] + A[15];
+        if (!std::isfinite(cy) || !std::isfinite(cw) || !std::isfinite(sy_abs) || !std::isfinite(sw_abs)) return false;
+        ey = std::max(ey, u16 * sy_abs); ew = std::max(ew, u16 * sw_abs);
+        if (!(cw > 0)) return false;                                                             // not in front: keep
+        wmin = std::min(wmin, cw);
+        const double ndc = cy / cw;
+        ndc_abs = std::max(ndc_abs, std::fabs(ndc));
+        const double sy = (1.0 - (ndc * 0.5 + 0.5)) * (double)c->H;                              // Rasterizer.cs:385-386
         if (!std::isfinite(sy)) return false;
         smin = std::min(smin, sy); smax = std::max(smax, sy);
     }
+    if (!(wmin - ew > 1e-6 * wmin)) return false;                       // the float32 w of some vertex may not be safely positive: keep
+    const double margin = 2.0 + 0.5 * (double)c->H * (ey + ndc_abs * ew) / (wmin - ew);
+    if (!std::isfinite(margin)) return false;
     const double y0 = (double)band_y0(c), y1 = (double)std::min(c->H, c->band_ty1 * SWR_TILE);   // band = pixel rows [y0, y1)
-    return smax < y0 - 2.0 || smin > y1 + 1.0;
+    return smax + margin < y0 || smin - margin > y1;
 }
 
 int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
@@ -780,10 +816,11 @@ int swr_create(int device_id, swr_context** out) {
     }
     c->stream = c->own_stream;
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
+    { const char* df = getenv("SWR_DEBUG_FILL_CAPACITY"); c->debug_fill_capacity = df ? (uint32_t)strtoul(df, nullptr, 10) : 0u; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_ctrl, 64);
     if (!rc && hipHostMalloc((void**)&c->host_poison, 64, hipHostMallocDefault) != hipSuccess) rc = SWR_ERR_OOM;
-    if (!rc) { *c->host_poison = 0; Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
+    if (!rc) { memset(c->host_poison, 0, 64); Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
     if (!rc) rc = ensure(c, c->d_total, 256 + 1024 * 8);
     if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 1024 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
@@ -1135,9 +1172,9 @@ int swr_render_mesh_arrays(swr_context* c, const swr_vertex* v, int nv, const ui
     swr_mesh* m = nullptr;
     int rc = make_mesh(c, v, nv, idx, ni, true, &m);
     if (rc) return rc;
-    const size_t before = c->draws.size();
     rc = record_draw(c, m, model, view, proj, program, u, tex, cull, depth_test, blend);
-    if (rc || c->draws.size() == before || c->draws.back().mesh != m) c->garbage.push_back(m);   // not referenced by a draw
+    // by identity (record_draw may have flushed the pending list first): a draw references m iff it is the last one recorded
+    if (rc || c->draws.empty() || c->draws.back().mesh != m) c->garbage.push_back(m);
     return rc;
 }
 
@@ -1162,6 +1199,7 @@ int swr_get_stats(swr_context* c, swr_stats* out) {
     SWR_ENTER(c);
     if (!out) return SWR_ERR_INVALID_ARG;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;          // validate (and replay) optimistic batches BEFORE the counters are gathered
     Counters host[65];
     unsigned long long frag[3] = { 0, 0, 0 };
     if (c->tile_stats_tiles) {
@@ -1222,6 +1260,7 @@ int swr_debug_counters(swr_context* c, uint64_t out[8]) {
     SWR_ENTER(c);
     if (!out) return SWR_ERR_INVALID_ARG;
     int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemcpyAsync(out, c->d_total.as<unsigned long long>() + 8, 64, hipMemcpyDeviceToHost, c->stream));
     if ((rc = sync_locked(c))) return rc;
     SWR_HIP(c, hipMemsetAsync(c->d_total.as<unsigned long long>() + 8, 0, 64, c->stream));

@@ -31,7 +31,9 @@ struct BinArgs {
     uint32_t* __restrict__ tile_list;
     uint32_t list_capacity;
     Counters* __restrict__ counters;
-    const Ctrl* __restrict__ ctrl;
+    Ctrl* __restrict__ ctrl;
+    uint32_t seq;                        // sequence number of the batch (what a list overflow reports in Ctrl::first_bad)
+    uint32_t replayable;                 // 1: optimistic flush -- a list overflow poisons the batch (see bin_overflow)
     const unsigned long long* __restrict__ total;
     uint8_t* __restrict__ want;          // per slot: which of its (<= 8) tiles passed pair_may_cover -- written by COUNT, read by FILL
     uint32_t tpw;                        // triangles per wave: 64, or fewer for small batches (a wave works through its big
@@ -82,6 +84,21 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
         any_pos = any_pos || (finite && emin > delta);
     }
     return !(any_neg && any_pos);
+}
+
+// A FILL position beyond the list capacity.  k_scan_apply already refuses batches whose COUNT total does not fit, so this
+// means COUNT and FILL disagreed (a bug) or a debug capacity (SWR_DEBUG_FILL_CAPACITY) -- either way the pair must not be
+// dropped silently: the sticky flag goes up, and in an optimistic flush the batch poisons itself BEFORE any of its later
+// kernels (sort, cover, raster all return on poison) touches the framebuffer, so the host replays it exactly.
+__device__ __forceinline__ void bin_overflow(const BinArgs& a) {
+    a.counters->overflow = 1u;
+    if (a.ctrl->host_flag) __hip_atomic_store(a.ctrl->host_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.replayable) {
+        atomicMin(&a.ctrl->first_bad, a.seq);
+        atomicMax(&a.ctrl->need, 2ull * (unsigned long long)a.list_capacity + 4096ull);
+        __hip_atomic_store(&a.ctrl->poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.ctrl->host_flag) __hip_atomic_store(a.ctrl->host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // what binning needs to know about one primitive slot
@@ -166,7 +183,7 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
                 if (want[j]) {
                     const uint32_t at = a.tile_start[tile[j]] + base[j];
                     if (at < a.list_capacity) a.tile_list[at] = sslot[j];
-                    else a.counters->overflow = 1u;
+                    else bin_overflow(a);
                 }
             }
         }
@@ -196,7 +213,7 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
                 if (FILL) {
                     const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
                     if (at < a.list_capacity) a.tile_list[at] = s_slot;
-                    else a.counters->overflow = 1u;
+                    else bin_overflow(a);
                 } else {
                     atomicAdd(&a.tile_count[tile], 1u);
                 }
@@ -261,7 +278,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                     } else if (FILL) {                                      // crowded table (many distinct tiles): go direct
                         const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
                         if (at < a.list_capacity) a.tile_list[at] = slot;
-                        else a.counters->overflow = 1u;
+                        else bin_overflow(a);
                     } else {
                         atomicAdd(&a.tile_count[tile], 1u);
                     }
@@ -289,7 +306,7 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                 if (packed[i] & 0x80000000u) {
                     const uint32_t at = s_val[packed[i] & 0xfffu] + ((packed[i] >> 12) & 0x7ffffu);
                     if (at < a.list_capacity) a.tile_list[at] = slot;
-                    else a.counters->overflow = 1u;
+                    else bin_overflow(a);
                 }
             }
         }

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     __shared__ uint32_t s_hist[34];           // work sort: pairs per area bucket, then bucket bases
     __shared__ uint16_t s_perm[256];          // sorted position -> thread whose pair it is
     __shared__ uint16_t s_cnt[256];           // coverage counts back in pair order
+    __shared__ uint32_t s_wmax[4];            // per wave: widest bbox /\ tile among its lanes on the fast path
     if (a.ctrl->poison) return;
     const uint32_t p_own = blockIdx.x * 256u + threadIdx.x;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
@@ -93,6 +94,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     // the block first sorts its 256 pairs by that area (counting sort in LDS): each wave then holds pairs of similar
     // length.  Results are written at the pair's own index, so nothing downstream sees the permutation.
     if (threadIdx.x < 34) s_hist[threadIdx.x] = 0u;
+    if (threadIdx.x < 4) s_wmax[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t bucket = 0, rank = 0;
     {
@@ -145,7 +147,11 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         // 39.3uS of the exact affine depth; that is maximal at a corner of R; the corners evaluated in float below are
         // within 7.3uS; margin used: 64uS.  Lines and non-finite cases get +inf (never hidden).
         float zbound = __uint_as_float(0x7f800000u);
+#ifndef SWR_ABL_NOZBOUND
         if (!is_line && startX <= endX && startY <= endY) {
+#else
+        if (false) {
+#endif
             const float fxs = (float)startX, fxe = (float)endX, fys = (float)startY, fye = (float)endY;
             const float sx[3] = { r0.x, r0.y, r0.z }, sy[3] = { r0.w, r1.x, r1.y };
             const float dd[3] = { r1.z, r1.w, r2.x };
@@ -193,16 +199,30 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
             const bool fast = fabsf(a12) < lim && fabsf(a20) < lim && fabsf(a01) < lim && fabsf(b12) < lim && fabsf(b20) < lim &&
                               fabsf(b01) < lim && fabsf(w0r) < lim && fabsf(w1r) < lim && fabsf(w2r) < lim;
             if (fast) {
-                const uint32_t bit0 = 1u << (startX - x0);
+                // The column loop runs a WAVE-UNIFORM number of steps (the widest box among this wave's lanes: a wave
+                // executes its longest lane anyway), so the per-pixel work is the three chain adds, the test and one
+                // shift-or -- no per-lane loop bookkeeping.  A narrower lane steps past its endX; those values are
+                // never looked at (colmask) and stay finite (<= 31 adds of values below 1e30).
+                const int width = endX - startX + 1;
+                atomicMax(&s_wmax[threadIdx.x >> 6], (uint32_t)width);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int wsteps = __builtin_amdgcn_readfirstlane((int)s_wmax[threadIdx.x >> 6]);
+                const uint32_t colmask = (1u << width) - 1u;
+                const int sh = startX - x0;
+#ifdef SWR_ABL_NOCOVERLOOP      // tools/ablate.py timing experiments only (wrong image by design)
+                for (int y = startY; y <= startY; ++y) {
+#else
                 for (int y = startY; y <= endY; ++y) {
+#endif
                     float w0 = w0r, w1 = w1r, w2 = w2r;
-                    uint32_t rowbits = 0, bit = bit0;
-                    for (int x = startX; x <= endX; ++x) {
+                    uint32_t acc = 0;                      // pixel startX + i ends at bit wsteps - 1 - i
+                    for (int i = 0; i < wsteps; ++i) {
                         const bool inside = fminf(fminf(w0, w1), w2) >= 0.0f || fmaxf(fmaxf(w0, w1), w2) <= 0.0f;   // :493-494
-                        rowbits |= inside ? bit : 0u;
-                        bit <<= 1;
+                        acc = (acc << 1) | (inside ? 1u : 0u);
                         w0 += a12; w1 += a20; w2 += a01;                                                  // :527-529
                     }
+                    const uint32_t rowbits = ((__brev(acc) >> (32 - wsteps)) & colmask) << sh;
                     mrow16[y - y0] = (uint16_t)rowbits;
                     w0r += b12; w1r += b20; w2r += b01;                                                   // :532-534
                 }
@@ -520,6 +540,10 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         ++dbg_batches;
 #endif
 
+        // the staging lanes' LDS writes above are read by OTHER lanes below: one wave, so the LDS unit already executes them
+        // in order -- the fence pair only stops the compiler from ever moving a read above a write it cannot see aliasing
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
         for (int pos = 0; pos < total;) {
@@ -568,6 +592,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
             L.touched[lane] = (lane == (pix_first & 63)) ? (1u << (pix_first >> 6)) : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the seeding store above -> the other lanes' atomics below
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             const uint32_t pbit = 1u << (pix >> 6);
             bool dup = false;
 #ifndef SWR_ABL_NOELECT

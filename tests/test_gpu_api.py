@@ -369,3 +369,82 @@ def test_exact_division_core_matches_ieee_division(device):
         assert r["sqrt_mismatches"] == 0
         total["divisions"] += r["divisions"]; total["sqrts"] += r["sqrts"]
     assert total["divisions"] > 2_000_000_000 and total["sqrts"] > 2_000_000_000
+
+
+def test_tile_list_overflow_poisons_the_batch_and_is_replayed_exactly(monkeypatch):
+    """Counters::overflow is no longer write-only: a list position beyond the capacity (forced here with the debug hook
+    SWR_DEBUG_FILL_CAPACITY, which makes k_bin<FILL> of an optimistic flush see a shorter list than COUNT was checked
+    against) poisons the batch before its raster kernel runs, and the host replays it synchronously: same frame, same counters."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    monkeypatch.setenv("SWR_DEBUG_FILL_CAPACITY", "500")
+    dev = Device(0)
+    monkeypatch.delenv("SWR_DEBUG_FILL_CAPACITY")
+    try:
+        scene = scenes.cfg3(320, 240, (3, 3), (20, 14), tex_size=64, seed=21)
+        o = OracleRenderer(scene.width, scene.height)
+        rc, rd = o.render_scene(scene)
+        rst = o.stats()
+        r = scenes.SceneRenderer(dev, scene)
+        r.render()                                   # synchronous flush: sizes the pair buffers (the hook does not apply)
+        dev.reset_stats()
+        c, d = r.render()                            # optimistic flush: FILL overflows its 500 entries -> poison -> replay
+        st = dev.stats()
+        r.close()
+        assert_frame_parity(c, d, rc, rd, 1, "fill overflow replay")
+        for k in ("triangles_in", "triangles_setup", "fragments_tested", "fragments_shaded", "fragments_written"):
+            assert st[k] == rst[k], (k, st[k], rst[k])
+    finally:
+        dev.close()
+
+
+def test_more_than_2_pow_20_tiles_is_refused_not_overrun(device):
+    """the tile-count scan holds 1024 x 1024 tiles; a larger unbanded target used to write past the block sums.
+    Now the draw is refused (SWR_ERR_UNSUPPORTED) and the same target renders in tile-row bands."""
+    from softwarerenderer_amd._native import SwrError, SWR_ERR_UNSUPPORTED
+    scene = scenes.cfg1()
+    win = MainWindow(device, 16400, 16400)              # 1025 x 1025 tiles
+    d0 = scene.draws[0]
+    prog = scenes.ShaderProgram(d0.program, d0.uniforms, None)
+    Rasterizer.RenderMesh(win, d0.vertices, d0.indices, d0.model, d0.view, d0.projection, prog.VertexShader, prog.FragmentShader,
+                          d0.cull, d0.depth_test, d0.blend)
+    with pytest.raises(SwrError) as e:
+        device.sync()
+    assert e.value.code == SWR_ERR_UNSUPPORTED
+    win.SetBand(256, 512)                                # the middle half: 1025 x 512 tiles
+    win.ClearColorBuffer((0, 0, 0, 1)); win.ClearDepthBuffer()
+    Rasterizer.RenderMesh(win, d0.vertices, d0.indices, d0.model, d0.view, d0.projection, prog.VertexShader, prog.FragmentShader,
+                          d0.cull, d0.depth_test, d0.blend)
+    device.sync()
+    assert device.stats()["fragments_written"] > 0
+    px = win.GetPixel(8200, 8200)                        # centre of the frame, inside the triangle and the band
+    assert px[3] == 1.0 and px[:3].sum() > 0
+    MainWindow(device, 64, 64)                           # release the 5 GB target
+
+
+def test_band_union_with_large_cancelling_translations(device):
+    """band_rejects projected the mesh box in double precision with a fixed 2-pixel margin, but the device (like
+    the reference) chains three float32 products; with model and view translations of 1e5 that cancel, float32 screen positions
+    move by many pixels.  The margin now carries the float32 error bound, so the union of the bands still equals the frame
+    rendered in one piece."""
+    import softwarerenderer_amd.hostmath as hm
+    scene = scenes.cfg3(300, 270, (3, 3), (20, 14), tex_size=64, seed=8)
+    t = 1.0e5
+    for d in scene.draws:
+        d.model = hm.multiply(d.model, hm.create_translation(t, -t, t))
+        d.view = hm.multiply(hm.create_translation(-t, t, -t), d.view)
+    whole = scenes.SceneRenderer(device, scene)
+    c0, d0 = whole.render()
+    whole.close()
+    assert (d0 != np.float32(-3.40282347e+38)).any()
+    for world in (2, 5):
+        cols, deps = [], []
+        for band in multigpu.band_partition(scene.height, world):
+            win = MainWindow(device, scene.width, scene.height)
+            win.SetBand(*band)
+            r = scenes.SceneRenderer(device, scene, window=win)
+            c, d = r.render()
+            r.close()
+            cols.append(c); deps.append(d)
+        assert np.array_equal(np.concatenate(deps).view(np.uint32), d0.view(np.uint32))
+        assert np.array_equal(np.concatenate(cols).view(np.uint32), c0.view(np.uint32))
