@@ -57,3 +57,101 @@ def test_package_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboswr" not in txt, f
+
+
+# ---- csharp/RasterizerNative.cs: the C# side of the boundary cannot be compiled here (no .NET), so it is checked mechanically ----
+CS = open(os.path.join(ROOT, "csharp", "RasterizerNative.cs")).read()
+
+
+def _split_params(plist):
+    plist = plist.strip()
+    if plist in ("", "void"):
+        return []
+    out, depth, cur = [], 0, ""
+    for ch in plist:
+        if ch in "([<":
+            depth += 1
+        elif ch in ")]>":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    out.append(cur.strip())
+    return out
+
+
+def header_prototypes():
+    src = open(os.path.join(ROOT, "include", "swr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return {m.group(1): _split_params(m.group(2)) for m in re.finditer(r"\b(swr_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)}
+
+
+def csharp_imports():
+    return {m.group(2): _split_params(m.group(3))
+            for m in re.finditer(r"\[DllImport\(Lib\)\]\s*public static extern\s+([\w\*]+)\s+(swr_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", CS)}
+
+
+def test_csharp_binding_declares_exactly_the_entry_points_of_swr_h():
+    protos, imports = header_prototypes(), csharp_imports()
+    assert sorted(imports) == sorted(protos) == sorted(_native.EXPORTS)
+    for name, params in protos.items():
+        assert len(imports[name]) == len(params), (name, params, imports[name])
+    # pointer-ness agrees argument by argument (a C pointer / array is `*`, `out`, or IntPtr on the C# side; a scalar is neither)
+    for name, params in protos.items():
+        for cp, sp in zip(params, imports[name]):
+            c_is_ptr = "*" in cp or "[" in cp
+            s_is_ptr = "*" in sp or sp.startswith("out ") or sp.startswith("IntPtr")
+            assert c_is_ptr == s_is_ptr, (name, cp, sp)
+
+
+CS_SIZES = {"float": 4, "double": 8, "ulong": 8, "int": 4, "Vector2": 8, "Vector3": 12, "Vector4": 16, "SwrPointLight": 32}
+
+
+def cs_struct(name):
+    body = re.search(r"public struct %s\b[^{]*\{(.*?)\n    \}" % name, CS, flags=re.S).group(1)
+    body = re.sub(r"//.*", "", body)
+    return [(m.group(2), m.group(1)) for m in re.finditer(r"public\s+(\w+)\s+(\w+)\s*;", body)]
+
+
+def snake(n):
+    return re.sub(r"(?<!^)(?=[A-Z])", "_", n).lower()
+
+
+def test_csharp_struct_layouts_equal_the_ctypes_ones():
+    pairs = {"SwrPointLight": _native.PointLight, "SwrUniforms": _native.Uniforms, "SwrStats": _native.Stats, "SwrProfile": _native.Profile}
+    for cs_name, ct in pairs.items():
+        fields = cs_struct(cs_name)
+        assert sum(CS_SIZES[t] for _, t in fields) == ctypes.sizeof(ct), cs_name
+        # field order: walk both in parallel by offset
+        off, got = 0, []
+        for n, t in fields:
+            got.append((off, CS_SIZES[t])); off += CS_SIZES[t]
+        want = []
+        for fname, ftype in ct._fields_:
+            f = getattr(ct, fname)
+            if cs_name == "SwrUniforms" and fname == "lights":
+                want += [(f.offset + 32 * i, 32) for i in range(4)]
+            else:
+                want.append((f.offset, f.size))
+        assert got == want, (cs_name, got, want)
+        names_cs = [snake(n).replace("pad", "_pad") for n, _ in fields if not n.startswith("Light") or cs_name != "SwrUniforms" or n in ("LightDirection", "LightColor")]
+        names_ct = [n for n, _ in ct._fields_ if n != "lights"]
+        assert names_cs == names_ct, (names_cs, names_ct)
+    # Shaders.VertexInput is used as swr_vertex directly: 48 sequential bytes (Vector3, Vector2, Vector3, Vector4)
+    assert 12 + 8 + 12 + 16 == ctypes.sizeof(_native.Vertex)
+
+
+def test_csharp_shim_keeps_the_reference_signature_and_enum_ordinals():
+    sig = re.search(r"public static unsafe void RenderMesh\(\s*MainWindow window,\s*Shaders\.VertexInput\[\] vertices,\s*ushort\[\] indices,\s*"
+                    r"Matrix4x4 model,\s*Matrix4x4 view,\s*Matrix4x4 projection,\s*Shaders\.VertexShader vertexShader,\s*"
+                    r"Shaders\.FragmentShader fragmentShader,\s*CullMode cullMode = CullMode\.Back,\s*DepthTest depthTest = DepthTest\.LessEqual,\s*"
+                    r"BlendMode blendMode = BlendMode\.Alpha\)", CS)
+    assert sig, "RenderMesh must keep the signature and defaults of Rasterizer.cs:163-174"
+    hdr = open(os.path.join(ROOT, "include", "swr.h")).read()
+    for cs, c in (("FlatColor = 0", "SWR_PROG_FLAT_COLOR = 0"), ("Gouraud = 1", "SWR_PROG_GOURAUD = 1"),
+                  ("Dust2LambertFog = 2", "SWR_PROG_DUST2_LAMBERT_FOG = 2"), ("Phong4Point = 3", "SWR_PROG_PHONG_4POINT = 3")):
+        assert cs in CS and c in hdr
+    for fwd in ("SetPixel", "GetPixel", "ClearColorBuffer", "SetDepth", "GetDepth", "ClearDepthBuffer", "Resize", "Present"):
+        assert re.search(r"public static \w+ %s\(" % fwd, CS), fwd          # MainWindow.cs:320-321,382-436 forwards
+    assert "class TextureNative : IDisposable" in CS and "public Vector4 Sample(Vector2 uv)" in CS and "public void Dispose()" in CS

@@ -6,6 +6,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 def test_cpp_host_mirror_parity():
@@ -16,3 +17,15 @@ def test_cpp_host_mirror_parity():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ALL OK" in r.stdout
+
+
+def test_plain_c_caller_renders_cfg1_through_the_abi():
+    """tests/c/abi_smoke.c: gcc + dlopen, no C++ / HIP headers -- resolves every declared symbol and renders BASELINE cfg1
+    through swr_render_mesh_arrays (the array form of the reference's RenderMesh signature)."""
+    import subprocess
+    from softwarerenderer_amd import _native
+    exe = os.path.join(ROOT, "tests", "c", "abi_smoke")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "c"), "-s"], check=True)
+    out = subprocess.run([exe, _native.LIB_PATH], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "covered=8321 wrong=0 depth_touched=0" in out.stdout
