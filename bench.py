@@ -54,9 +54,14 @@ def main():
     ap.add_argument("--fake-world", type=int, default=0,
                     help="self-test of the N>1 code path in ONE process: act as rank 0 of N, collectives stubbed (numbers are meaningless)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not record hipEvents around kernels in the timed region")
-    ap.add_argument("--gather", choices=["rgb32f", "rgba32f"], default="rgb32f",
-                    help="N>1: what rank 0 gathers per frame -- rgb32f = the present payload of MainWindow.OnRender "
-                         "(Vector4 -> Vector3 flatten, 12 B/pixel), rgba32f = the raw colour buffer (16 B/pixel)")
+    ap.add_argument("--gather", choices=["rgb32f", "rgba32f", "p2p"], default="rgb32f",
+                    help="N>1: what reaches rank 0 per frame and how -- rgb32f = the present payload of MainWindow.OnRender "
+                         "(Vector4 -> Vector3 flatten, 12 B/pixel) by an RCCL gather, rgba32f = the raw colour buffer (16 B/pixel) "
+                         "by an RCCL gather, p2p = the rgb32f payload stored by every rank's flatten kernel straight into rank 0's "
+                         "frame through a peer-mapped (IPC) pointer over xGMI: no collective in the data path, one barrier per frame")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; gloo (control plane only, needs --gather p2p) rehearses the N>1 path with "
+                         "several ranks on ONE GPU (SWR_BENCH_ONE_DEVICE=1), which RCCL refuses")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -83,10 +88,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if os.environ.get("SWR_BENCH_ONE_DEVICE", "0") == "1":
+        local_rank = 0                    # rehearsal: every rank on GPU 0 (at most 6 processes may share a card on this pool)
     torch.cuda.set_device(local_rank)
     if world > 1 and not args.fake_world:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            if args.gather != "p2p":
+                raise SystemExit("--backend gloo carries no GPU payload: use it with --gather p2p")
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import numpy as np
     from softwarerenderer_amd import Device, MainWindow, multigpu, scenes
@@ -105,16 +117,64 @@ def main():
         depth_t = [torch.zeros((rows, W), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
         window.SetBand(*band)
         window.BindFramebuffer(color_t[0].data_ptr(), depth_t[0].data_ptr())
-    rgb = world > 1 and args.gather == "rgb32f"
+    p2p = world > 1 and args.gather == "p2p"
+    rgb = world > 1 and args.gather in ("rgb32f", "p2p")
     chan = 3 if rgb else 4
-    rgb_t = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(len(color_t))] if rgb else None
+    rgb_t = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(len(color_t))] if (rgb and not p2p) else None
     frame_t = torch.empty((H, W, chan), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    peer_rows = None
+    if world > 1:
+        # render, flatten and the consumer of the band run in stream order on torch's current stream: no host round trip
+        # between a frame's last kernel and its gather (optimistic flushes are validated later, see validate_previous)
+        # (a stream of its own: torch's default stream is the NULL stream, which swr_set_stream reads as "context's own")
+        side = torch.cuda.Stream()
+        torch.cuda.set_stream(side)
+        dev.set_stream(side.cuda_stream)
+    if p2p:
+        # rank 0 shares its frame (one IPC handle, exchanged once); every rank maps it and its flatten kernel stores the
+        # band's rows directly into it over xGMI
+        from torch.multiprocessing.reductions import reduce_tensor
+        box = [reduce_tensor(frame_t) if rank == 0 else None]
+        if not args.fake_world:
+            dist.broadcast_object_list(box, src=0)
+        if rank == 0:
+            peer_frame = frame_t
+        else:
+            fn, fargs = box[0]
+            peer_frame = fn(*fargs)                        # hipIpcOpenMemHandle (lazy peer access) inside torch
+        y0, nrows = multigpu.band_pixel_rows(H, band)
+        peer_rows = peer_frame[y0:y0 + nrows]              # contiguous rows of rank 0's frame = this rank's band
     renderer = scenes.SceneRenderer(dev, scene, window=window)
-    state = {"i": 0, "pending": None, "render_s": 0.0}
+    state = {"i": 0, "pending": None, "render_ms": 0.0, "ev": [], "replays": dev.replay_count() if world > 1 else 0, "resent": 0}
+
+    def send_band(k):
+        """flatten (on the GPU) + hand the band of buffer k to rank 0; everything stream-ordered behind the frame's kernels"""
+        if p2p:
+            window.FlattenToAsync(peer_rows.data_ptr())
+            return
+        if rgb:
+            window.FlattenToAsync(rgb_t[k].data_ptr())     # present payload: Vector4 -> Vector3 on the GPU (MainWindow.cs:234-240)
+        multigpu.gather_bands(rgb_t[k] if rgb else color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+
+    def validate_previous():
+        """The stream has drained: let the backend look at its optimistic batches.  If one had not fitted (never in steady
+        state) swr_sync has replayed it into the buffer it was flushed against; the payload sent meanwhile was stale: resend."""
+        dev.sync()
+        r = dev.replay_count()
+        if r != state["replays"] and state["pending"] is not None:
+            state["replays"] = r
+            k = state["pending"]
+            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
+            send_band(k)
+            torch.cuda.current_stream().synchronize()
+            state["resent"] += 1
 
     def wait_gather():
         if state["pending"] is not None:
             torch.cuda.current_stream().synchronize()      # the previous frame's bands have arrived / been sent
+            if p2p and not args.fake_world:
+                dist.barrier()                              # every rank's stores into rank 0's frame have completed
+            validate_previous()
             state["pending"] = None
 
     def barrier():
@@ -132,19 +192,20 @@ def main():
         k = state["i"] % len(color_t)
         state["i"] += 1
         if len(color_t) > 1:
-            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
-        t_r = time.perf_counter()
+            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())     # no host wait (a batch remembers its target)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         renderer.submit_frame()
-        if rgb:
-            window.FlattenTo(rgb_t[k].data_ptr())     # present payload: Vector4 -> Vector3 on the GPU (MainWindow.cs:234-240)
-        dev.sync()            # the band must be final (optimistic flushes are validated here) before RCCL reads it
-        state["render_s"] += time.perf_counter() - t_r
+        dev.flush()
+        e1.record()                                         # render leg of this rank, on the stream the kernels run on
+        state["ev"].append((e0, e1))
         wait_gather()         # one gather in flight at a time (it fills the same frame on rank 0)
-        multigpu.gather_bands(rgb_t[k] if rgb else color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+        send_band(k)
         if overlap:
             state["pending"] = k          # completes while the next frame renders into the other buffer
         else:
-            torch.cuda.current_stream().synchronize()
+            state["pending"] = k
+            wait_gather()
 
     # Setup (untimed, not part of warmup): the first frame sizes the pair buffers synchronously, and the HIP runtime
     # that torch bundles spends a one-off ~45 ms around its 16th submission (measured: tools/host_timing2.py) growing
@@ -165,13 +226,13 @@ def main():
         dev.profile_reset()
         dev.profile_enable(2)          # hipEvents around the dominant kernel only: every event pair costs ~10 us of stream time
     barrier()
-    state["render_s"] = 0.0
+    state["ev"] = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    render_s = state["render_s"]
+    render_s = 1e-3 * sum(a.elapsed_time(b) for a, b in state["ev"]) if world > 1 else 0.0
     prof = dev.profile() if not args.no_profile_events else None
     st = dev.stats()
     stage_ms = None
@@ -188,8 +249,9 @@ def main():
         dev.profile_enable(0)
 
     # whole-job numbers: max time over ranks, fragments summed over ranks
-    counts = torch.tensor([st["fragments_tested"], st["fragments_written"], st["tile_pairs"]], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed, render_s], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if (world > 1 and args.backend == "gloo" and not args.fake_world) else "cuda"
+    counts = torch.tensor([st["fragments_tested"], st["fragments_written"], st["tile_pairs"]], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed, render_s], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -216,7 +278,8 @@ def main():
                                    f"{'2048^2 RGBA8 nearest texture, ' if scene.textures else ''}"
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
-                       "parallelism": "1 GPU" if world == 1 else f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0"
+                       "parallelism": "1 GPU" if world == 1 else (f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0" if not p2p else
+                                      f"{world} tile-row bands, each rank's flatten kernel stores its rgb32f band into rank 0's frame through a peer-mapped pointer (xGMI), one barrier per frame")
                                       + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")},
             "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
             "fragments_tested_per_frame": int(frags_tested),
@@ -228,7 +291,7 @@ def main():
             # the two legs of a multi-GPU step: rendering the bands (slowest rank, wall time until its band is final)
             # and the xGMI gather of the frame into rank 0, which overlaps the next frame's rendering
             out["multi_gpu"] = {"render_ms_per_step": round(1e3 * render_s / args.steps, 4),
-                                "gather_payload": args.gather,
+                                "gather_payload": args.gather, "frames_resent_after_replay": state["resent"],
                                 "gather_mb_per_frame_into_rank0": round(H * W * chan * 4 * (world - 1) / world / 1e6, 1)}
         if prof is not None and prof["raster_launches"] > 0:
             # dominant kernel = k_raster; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1)
@@ -252,9 +315,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(scene, renderer, np)
         print(json.dumps(out), flush=True)
 
+    if rank == 0 and world > 1 and os.environ.get("SWR_BENCH_DUMP_FRAME"):     # tests: the frame rank 0 holds after the last step
+        np.save(os.environ["SWR_BENCH_DUMP_FRAME"], frame_t.cpu().numpy())
     renderer.close()
     dev.close()
-    if world > 1:
+    if world > 1 and not args.fake_world:
         dist.destroy_process_group()
 
 

@@ -85,7 +85,7 @@ namespace SoftwareRenderer
 
     public enum SwrProgram { FlatColor = 0, Gouraud = 1, Dust2LambertFog = 2, Phong4Point = 3 }
 
-    // ---------------------------------------------------------------- the 46 entry points ----
+    // ---------------------------------------------------------------- the 48 entry points ----
     // Shaders.VertexInput (Shaders.cs:10-24) IS swr_vertex: four sequential System.Numerics fields, 48 bytes, blittable.
     // Matrix4x4 is 16 sequential floats M11..M44 (row-major, row-vector convention): passed by address, no marshalling.
     internal static unsafe class Native
@@ -108,6 +108,8 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_readback(IntPtr ctx, Vector4* colorRgba, float* depth);
         [DllImport(Lib)] public static extern int swr_readback_rgb(IntPtr ctx, Vector3* rgb);
         [DllImport(Lib)] public static extern int swr_flatten_rgb_device(IntPtr ctx, IntPtr deviceRgb);
+        [DllImport(Lib)] public static extern int swr_flatten_rgb_device_async(IntPtr ctx, IntPtr deviceRgb);
+        [DllImport(Lib)] public static extern int swr_replay_count(IntPtr ctx, out ulong replays);
         [DllImport(Lib)] public static extern int swr_host_register(IntPtr ctx, void* ptr, nuint bytes);
         [DllImport(Lib)] public static extern int swr_host_unregister(IntPtr ctx, void* ptr);
         [DllImport(Lib)] public static extern int swr_upload(IntPtr ctx, Vector4* colorRgba, float* depth);

@@ -122,7 +122,8 @@ int  swr_resize(swr_context* ctx, int width, int height);
  * W x H frame; its buffers hold just those rows.  Default = whole frame. */
 int  swr_set_band(swr_context* ctx, int first_tile_row, int n_tile_rows);
 /* use caller-provided device memory (e.g. a torch tensor that RCCL will gather) for the band's
- * colour (float4 per pixel) and depth (float per pixel); NULL returns to internal storage */
+ * colour (float4 per pixel) and depth (float per pixel); NULL returns to internal storage.  Draws recorded before the
+ * call are launched against the buffers bound before it; the call itself does not wait for the GPU. */
 int  swr_bind_framebuffer(swr_context* ctx, void* color_device_ptr, void* depth_device_ptr);
 int  swr_set_stream(swr_context* ctx, void* hip_stream);      /* hipStream_t; NULL = context's own stream */
 int  swr_clear_color(swr_context* ctx, const float rgba[4]);   /* MainWindow.ClearColorBuffer, MainWindow.cs:400-407 */
@@ -141,6 +142,13 @@ int  swr_readback_rgb(swr_context* ctx, float* rgb);
  * draws on the context's stream and NOT synchronised: swr_sync (or the caller's own stream order) completes it.  This is
  * the present payload a multi-GPU frame gathers over xGMI (12 instead of 16 B per pixel). */
 int  swr_flatten_rgb_device(swr_context* ctx, float* d_rgb);
+/* The same flatten WITHOUT validating the optimistic flushes first: nothing here waits for the GPU, so a frame loop can
+ * chain render -> flatten -> its own consumer (an RCCL gather, a peer-mapped store target) in stream order.  The caller
+ * validates later -- swr_sync at a point where it waits anyway -- and compares swr_replay_count before / after: if it grew,
+ * a batch had not fitted its pair buffers, was replayed by that swr_sync, and payloads flattened in between are stale
+ * (flatten and send them again).  Steady-state frames never replay. */
+int  swr_flatten_rgb_device_async(swr_context* ctx, float* d_rgb);
+int  swr_replay_count(swr_context* ctx, uint64_t* out);
 /* Page-lock a long-lived host buffer (the C# side's pinned ColorBuffer / flatColorBuffer arrays) so that swr_readback /
  * swr_readback_rgb / swr_upload DMA straight into it at PCIe rate instead of going through a pageable staging copy.
  * Optional: unregistered buffers work, only slower.  Unregister before freeing the memory. */

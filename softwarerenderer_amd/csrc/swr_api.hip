@@ -74,6 +74,8 @@ struct Batch {
     float near_clip = 0.1f;
     bool wireframe = false;                    // Rasterizer.RenderDebugMode == Wireframe for the whole batch
     uint32_t seq = 0;
+    float4* color = nullptr;                   // the framebuffer bound when the batch was flushed: a replay (validate_locked) must
+    float* depth = nullptr;                    // hit the same buffers even if the caller has bound others since (double buffering)
 };
 
 }  // namespace
@@ -290,13 +292,13 @@ int ensure_pairs(swr_context* c, size_t n) {
     return ensure(c, c->d_pcounts, n * 8 + 64);
 }
 
-int run_clear(swr_context* c, bool& cc, bool& cd, const float rgba_[4]) {
+int run_clear(swr_context* c, const Batch& b, bool& cc, bool& cd, const float rgba_[4]) {
     size_t n = band_pixels(c);
     if (n && (cc || cd)) {
         ScopedSpan sp(c, ST_CLEAR);
         int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
         float4 rgba = make_float4(rgba_[0], rgba_[1], rgba_[2], rgba_[3]);
-        hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, c->stream, c->color, c->depth, n, rgba,
+        hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, c->stream, b.color, b.depth, n, rgba,
                            cc ? 1 : 0, cd ? 1 : 0, (const Ctrl*)c->d_ctrl.as<Ctrl>());
         SWR_HIP(c, hipGetLastError());
     }
@@ -372,7 +374,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
             return bin_and_raster(c, b, cc, cd, mid, hi, mode);
         }
         Counters* tp = c->d_counters.as<Counters>() + 64;          // tile_pairs of a round that really runs
-        if (total == 0) return run_clear(c, cc, cd, b.clear_rgba);
+        if (total == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
         if (total > 0xffffffffull) return fail(c, SWR_ERR_UNSUPPORTED, "a single triangle covers more tile pairs than one round can hold");
         c->host_tile_pairs += total; (void)tp;
         // a little headroom so that the next, similar frame can run without reading the total back
@@ -435,7 +437,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.tile_start = c->d_tile_start.as<uint32_t>();
         ra.tile_count = c->d_tile_count.as<uint32_t>();
         ra.pair_refs = c->d_pair_refs.as<uint4>();
-        ra.color = c->color; ra.depth = c->depth;
+        ra.color = b.color; ra.depth = b.depth;
         ra.tile_stats = c->d_tile_stats.as<uint32_t>();
         memcpy(ra.clear_rgba, b.clear_rgba, 16);
         ra.clear_color_on = cc ? 1 : 0;
@@ -482,7 +484,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
 // launches one batch (clears + draws) on the stream
 int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     bool cc = b.clear_color, cd = b.clear_depth;
-    if (b.draws.empty()) return run_clear(c, cc, cd, b.clear_rgba);
+    if (b.draws.empty()) return run_clear(c, b, cc, cd, b.clear_rgba);
     int rc;
     const size_t nd = b.draws.size();
     std::vector<DrawParams> hp(nd);
@@ -499,7 +501,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const uint64_t spt = b.wireframe ? 6 : 2;        // primitive slots per submitted triangle
     if (V + 4 * T >= 0xffffffffull || spt * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
-    if (T == 0) return run_clear(c, cc, cd, b.clear_rgba);
+    if (T == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
     // the per-tile scan (k_scan_sums / k_scan_apply) holds 1024 block sums of 1024 tiles each
     if (n_tiles > (1u << 20))
@@ -569,7 +571,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode);
     slot_submit(c);
     if (rc) return rc;
-    if (cc || cd) return run_clear(c, cc, cd, b.clear_rgba);   // nothing was binned
+    if (cc || cd) return run_clear(c, b, cc, cd, b.clear_rgba);   // nothing was binned
     return SWR_OK;
 }
 
@@ -631,6 +633,7 @@ int flush_locked(swr_context* c) {
     b.near_clip = c->near_clip;
     b.wireframe = c->debug_mode == SWR_DEBUG_WIREFRAME;
     b.seq = c->next_seq++;
+    b.color = c->color; b.depth = c->depth;
     c->pend_clear_color = c->pend_clear_depth = false;
     c->pend_verts = c->pend_tris = 0;
     if (!b.draws.empty()) c->totals.flushes++;
@@ -878,10 +881,12 @@ int swr_set_band(swr_context* c, int first_tile_row, int n_tile_rows) {
 
 int swr_bind_framebuffer(swr_context* c, void* color, void* depth) {
     SWR_ENTER(c);
+    if ((color == nullptr) != (depth == nullptr)) return fail(c, SWR_ERR_INVALID_ARG, "bind both colour and depth, or neither");
+    // draws recorded so far belong to the buffers bound so far: launch them (asynchronously -- a batch remembers its
+    // target, so neither the switch nor a later replay needs the stream to drain; a frame loop that alternates two band
+    // buffers pays no host round trip here)
     int rc = flush_locked(c);
     if (rc) return rc;
-    if ((rc = sync_locked(c))) return rc;
-    if ((color == nullptr) != (depth == nullptr)) return fail(c, SWR_ERR_INVALID_ARG, "bind both colour and depth, or neither");
     c->ext_color = color; c->ext_depth = depth;
     return apply_geometry(c);
 }
@@ -980,6 +985,26 @@ int swr_flatten_rgb_device(swr_context* c, float* d_rgb) {
     int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
     hipLaunchKernelGGL(k_flatten_rgb, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->color, d_rgb, n);
     SWR_HIP(c, hipGetLastError());
+    return SWR_OK;
+}
+
+int swr_flatten_rgb_device_async(swr_context* c, float* d_rgb) {
+    SWR_ENTER(c);
+    if (!d_rgb) return fail(c, SWR_ERR_INVALID_ARG, "d_rgb is null");
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    size_t n = band_pixels(c);
+    if (!n) return SWR_OK;
+    int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
+    hipLaunchKernelGGL(k_flatten_rgb, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->color, d_rgb, n);
+    SWR_HIP(c, hipGetLastError());
+    return SWR_OK;
+}
+
+int swr_replay_count(swr_context* c, uint64_t* out) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    *out = c->replays;
     return SWR_OK;
 }
 

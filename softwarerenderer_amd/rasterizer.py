@@ -161,6 +161,11 @@ class Device:
         keys = ("divisions", "division_mismatches", "sqrts", "sqrt_mismatches", "bad_n_bits", "bad_d_bits", "bad_got_bits", "bad_want_bits")
         return dict(zip(keys, (int(v) for v in out)))
 
+    def replay_count(self) -> int:
+        out = C.c_uint64(0)
+        self._ck(self._lib.swr_replay_count(self._ctx, C.byref(out)))
+        return int(out.value)
+
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.swr_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
@@ -337,6 +342,12 @@ class MainWindow:
         """FlatColorBuffer into caller-owned DEVICE memory (band rows x W x 3 floats); completes with Device.sync()."""
         self._activate()
         self._dev._ck(self._dev._lib.swr_flatten_rgb_device(self._dev._ctx, C.c_void_p(device_ptr)))
+
+    def FlattenToAsync(self, device_ptr: int):
+        """FlattenTo without the validation sync (swr_flatten_rgb_device_async): for frame loops that chain render -> flatten
+        -> gather in stream order and validate later with Device.sync() + Device.replay_count()."""
+        self._activate()
+        self._dev._ck(self._dev._lib.swr_flatten_rgb_device_async(self._dev._ctx, C.c_void_p(device_ptr)))
 
     def Upload(self, color=None, depth=None):
         self._activate()

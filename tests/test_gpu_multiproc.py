@@ -1,0 +1,44 @@
+"""The N>1 path with REAL processes on the one GPU of the test box: two ranks (gloo as the control plane, both on cuda:0)
+render the two tile-row bands of a frame and store their flattened bands into rank 0's frame through a peer-mapped IPC pointer
+(`bench.py --gather p2p`, the direct-store variant of SURVEY.md section 8e); rank 0 then holds the whole present payload.
+RCCL itself refuses two ranks on one device, so the RCCL gather is covered by the gloo CPU test (tests/test_multigpu_gloo.py)
+and `bench.py --fake-world`; a multi-GPU node is the driver's to run."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_store_their_bands_into_rank0s_frame(tmp_path):
+    out = tmp_path / "frame.npy"
+    env = dict(os.environ, SWR_BENCH_ONE_DEVICE="1", SWR_BENCH_DUMP_FRAME=str(out), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3_small", "--steps", "3",
+           "--warmup", "1", "--prime", "2", "--gather", "p2p", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["multi_gpu"]["gather_payload"] == "p2p" and line["multi_gpu"]["frames_resent_after_replay"] == 0
+    # the frame rank 0 ended up with == the Vector4 -> Vector3 flatten of the single-GPU frame
+    from softwarerenderer_amd import Device, scenes
+    got = np.load(out)
+    scene = scenes.cfg3(1024, 1024, (4, 4), (64, 32), tex_size=512)
+    dev = Device(0)
+    rr = scenes.SceneRenderer(dev, scene)
+    c, _ = rr.render()
+    rr.close(); dev.close()
+    assert got.shape == (1024, 1024, 3)
+    assert np.array_equal(got.view(np.uint32), c[..., :3].view(np.uint32))
