@@ -24,6 +24,18 @@
 
 namespace swr {
 
+// Wave-synchronous LDS hand-off point: lanes write LDS above it, OTHER lanes of the same wave read below it.
+//  * hardware: one wave's LDS instructions execute in issue order, so a later ds_read sees an earlier ds_write of any lane;
+//  * compiler: program order between the write and the read is kept because the two accesses MAY alias (same LDS array,
+//    unrelated run-time indices) -- no pass may swap a store with a later load it cannot prove disjoint.
+// So the marker expands to nothing, deliberately.  Every real barrier was measured and rejected: a wavefront-scope
+// release/acquire fence (also the LDS-only form), __builtin_amdgcn_wave_barrier() and __builtin_amdgcn_sched_barrier(0)
+// all make LLVM treat the per-draw constants as clobberable, which turns their scalar loads (s_load through the constant
+// cache, 28 in the DUST2 kernel) into vector loads (16 left) with a vmcnt(0) wait in every chunk: k_raster_c 0.46 -> 0.58 ms
+// on cfg3 (gpurun_out/ab_r02j.txt).  An `asm volatile` block in the batch loop has the same kind of cost (it drains the
+// window prefetch at the loop top): wave_min's DPP ladder is a plain `asm` for that reason.
+#define SWR_WAVE_LDS_SYNC() ((void)0)
+
 // Inclusive prefix sum over the wave, on the DPP path (no LDS round trips): Hillis-Steele inside each row of 16 lanes
 // with row_shr, then the row totals with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3).  All 64 lanes must be active.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -205,8 +217,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
                 // never looked at (colmask) and stay finite (<= 31 adds of values below 1e30).
                 const int width = endX - startX + 1;
                 atomicMax(&s_wmax[threadIdx.x >> 6], (uint32_t)width);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                SWR_WAVE_LDS_SYNC();
                 const int wsteps = __builtin_amdgcn_readfirstlane((int)s_wmax[threadIdx.x >> 6]);
                 const uint32_t colmask = (1u << width) - 1u;
                 const int sh = startX - x0;
@@ -419,8 +430,19 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0, dbg_hidden = 0;
 #endif
 
+    // Rolling batch: a batch's fragment count is rarely a multiple of 64, and a partial last chunk costs a full chunk's
+    // instructions.  While the tile's list has more pairs, the tail of a batch (its last fewer-than-64 fragments and the
+    // few pairs they belong to) is carried into the next batch instead: their staged rows move to the first slots, the new
+    // survivors are staged behind them, and the stream continues with full chunks.  Fragment order is untouched.
+    // (Not with the BlendMode.None early-out, whose carry keys name pairs by batch.)
+#ifdef SWR_NO_ROLL
+    const bool ROLL = false;
+#else
+    const bool ROLL = !EARLYOUT;
+#endif
+    int carry_pairs = 0, carry_frags = 0;              // wave-uniform
     uint32_t batch_no = 0;
-    for (uint32_t base = 0; base < n; ++batch_no) {
+    for (uint32_t base = 0; base < n || carry_pairs > 0; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
         //      of the window are staged in LDS ----
         const uint32_t pidx = start + base + (uint32_t)lane;
@@ -452,7 +474,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         {
             const unsigned long long surv = __ballot(cnt > 0);
             const int rank = __popcll(surv & ((1ull << lane) - 1ull));
-            const unsigned long long last = __ballot(cnt > 0 && rank == SWR_BATCH - 1);
+            const unsigned long long last = __ballot(cnt > 0 && rank == SWR_BATCH - 1 - carry_pairs);
             consumed = last ? __ffsll((long long)last) : min(SWR_WINDOW, (int)(n - base));
             if (lane >= consumed) cnt = 0;
         }
@@ -478,12 +500,13 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
             }
         }
-        const int cincl = wave_incl_scan(cnt, lane);
+        const int cincl = wave_incl_scan(cnt, lane) + carry_frags;           // carried fragments come first in the stream
         const int total = __builtin_amdgcn_readlane(cincl, 63);
         if (total == 0) continue;
         const unsigned long long nzb = __ballot(cnt > 0);
-        const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
-        if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        const int ci = carry_pairs + __popcll(nzb & ((1ull << lane) - 1ull));   // slot of this lane's pair (carried pairs hold the first slots)
+        const int n_staged = carry_pairs + __popcll(nzb);
+        if (carry_pairs == 0 && lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
             // one round trip: masks, TriRec and the three outputs of every surviving pair
             const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
@@ -542,11 +565,13 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 
         // the staging lanes' LDS writes above are read by OTHER lanes below: one wave, so the LDS unit already executes them
         // in order -- the fence pair only stops the compiler from ever moving a read above a write it cannot see aliasing
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        SWR_WAVE_LDS_SYNC();
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
-        for (int pos = 0; pos < total;) {
+        int pos = 0;
+        for (; pos < total;) {
+            // fewer than 64 fragments left, more pairs in the list, and the tail spans few pairs: carry it (see ROLL)
+            if (ROLL && total - pos < 64 && base < n && n_staged - t0 <= SWR_BATCH / 2) break;
             const int g = pos + lane;
             const bool valid = g < total;
             // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
@@ -592,8 +617,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
             L.touched[lane] = (lane == (pix_first & 63)) ? (1u << (pix_first >> 6)) : 0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the seeding store above -> the other lanes' atomics below
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            SWR_WAVE_LDS_SYNC();      // the seeding store above -> the other lanes' atomics below
             const uint32_t pbit = 1u << (pix >> 6);
             bool dup = false;
 #ifndef SWR_ABL_NOELECT
@@ -725,6 +749,44 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 }
             }
             pos += cut;
+        }
+        // ---- carry the unconsumed tail into the next batch (ROLL) ----
+        carry_pairs = 0; carry_frags = 0;
+        if (ROLL && pos < total) {
+            const int t_first = t0;                         // the pair fragment `pos` belongs to
+            const int r = n_staged - t_first;               // 1 .. SWR_BATCH / 2 pairs
+            SWR_WAVE_LDS_SYNC();
+            // new stream positions of the carried pairs (the first one may have started before `pos`: negative is fine)
+            int np = 0;
+            if (lane < r) np = (int)L.pre[t_first + lane] - pos;
+            if (t_first > 0) {
+                // move their staged rows down to slots 0 .. r-1: 32 row slots per pair = NQ stage rows, the mask (2), wpre (1);
+                // every lane reads before any lane writes, and slot j < slot t_first + j, so nothing is overwritten early
+                for (int i0 = 0; i0 < r * 32; i0 += 64) {
+                    const int i = i0 + lane, j = i >> 5, q = i & 31, src = t_first + j;
+                    const bool on = i < r * 32 && q < WaveLdsC<PHONG>::NQ + 3;
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (on) {
+                        if (q < WaveLdsC<PHONG>::NQ) v = *reinterpret_cast<const uint4*>(&L.stage[q][src]);
+                        else if (q < WaveLdsC<PHONG>::NQ + 2) v = *reinterpret_cast<const uint4*>(&L.mask[src][4 * (q - WaveLdsC<PHONG>::NQ)]);
+                        else v = *reinterpret_cast<const uint4*>(&L.wpre[src][0]);
+                    }
+                    SWR_WAVE_LDS_SYNC();
+                    if (on) {
+                        if (q < WaveLdsC<PHONG>::NQ) *reinterpret_cast<uint4*>(&L.stage[q][j]) = v;
+                        else if (q < WaveLdsC<PHONG>::NQ + 2) *reinterpret_cast<uint4*>(&L.mask[j][4 * (q - WaveLdsC<PHONG>::NQ)]) = v;
+                        else *reinterpret_cast<uint4*>(&L.wpre[j][0]) = v;
+                    }
+                    SWR_WAVE_LDS_SYNC();
+                }
+            }
+            if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+            SWR_WAVE_LDS_SYNC();
+            if (lane < r) {
+                L.pre[lane] = (uint32_t)np;
+                if (lane > 0) atomicOr(&L.head[(uint32_t)(np - 1) >> 5], 1u << ((uint32_t)(np - 1) & 31u));      // np >= 1 for every later pair
+            }
+            carry_pairs = r; carry_frags = total - pos;
         }
     }
 
