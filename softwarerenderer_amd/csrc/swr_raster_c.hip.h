@@ -430,16 +430,16 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0, dbg_hidden = 0;
 #endif
 
-    // Rolling batch: a batch's fragment count is rarely a multiple of 64, and a partial last chunk costs a full chunk's
+    // Rolling batch (build with -DSWR_ROLL; OFF by default, see below): a batch's fragment count is rarely a multiple of 64, and a partial last chunk costs a full chunk's
     // instructions.  While the tile's list has more pairs, the tail of a batch (its last fewer-than-64 fragments and the
     // few pairs they belong to) is carried into the next batch instead: their staged rows move to the first slots, the new
     // survivors are staged behind them, and the stream continues with full chunks.  Fragment order is untouched.
     // (Not with the BlendMode.None early-out, whose carry keys name pairs by batch.)
-#ifdef SWR_NO_ROLL
-    const bool ROLL = false;
-#else
+#ifdef SWR_ROLL
     const bool ROLL = !EARLYOUT;
-#endif
+#else
+    const bool ROLL = false;         // measured on cfg3 (gpurun_out/ab_r02l.txt): chunks -7.7 % (62.5 instead of 57.8 fragments per chunk) but
+#endif                               // batches +19 % (a refill stages 16 - carried pairs): k_raster_c 0.456 -> 0.473 ms.  Kept for re-measurement only.
     int carry_pairs = 0, carry_frags = 0;              // wave-uniform
     uint32_t batch_no = 0;
     for (uint32_t base = 0; base < n || carry_pairs > 0; ++batch_no) {
