@@ -85,7 +85,7 @@ namespace SoftwareRenderer
 
     public enum SwrProgram { FlatColor = 0, Gouraud = 1, Dust2LambertFog = 2, Phong4Point = 3 }
 
-    // ---------------------------------------------------------------- the 48 entry points ----
+    // ---------------------------------------------------------------- the 49 entry points ----
     // Shaders.VertexInput (Shaders.cs:10-24) IS swr_vertex: four sequential System.Numerics fields, 48 bytes, blittable.
     // Matrix4x4 is 16 sequential floats M11..M44 (row-major, row-vector convention): passed by address, no marshalling.
     internal static unsafe class Native
@@ -97,6 +97,7 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern void swr_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern int swr_resize(IntPtr ctx, int width, int height);
         [DllImport(Lib)] public static extern int swr_set_band(IntPtr ctx, int firstTileRow, int nTileRows);
+        [DllImport(Lib)] public static extern int swr_set_band_interleaved(IntPtr ctx, int rank, int world, int stripeTileRows);
         [DllImport(Lib)] public static extern int swr_bind_framebuffer(IntPtr ctx, IntPtr colorDevicePtr, IntPtr depthDevicePtr);
         [DllImport(Lib)] public static extern int swr_set_stream(IntPtr ctx, IntPtr hipStream);
         [DllImport(Lib)] public static extern int swr_clear_color(IntPtr ctx, Vector4* rgba);

@@ -121,6 +121,10 @@ int  swr_resize(swr_context* ctx, int width, int height);
 /* multi-GPU: this context renders only tile rows [first_tile_row, first_tile_row + n_tile_rows) of the
  * W x H frame; its buffers hold just those rows.  Default = whole frame. */
 int  swr_set_band(swr_context* ctx, int first_tile_row, int n_tile_rows);
+/* multi-GPU, interleaved variant (load balance for clustered scenes): the frame's tile rows are cut into stripes of
+ * `stripe_tile_rows` rows and stripe s belongs to rank s % world; this context renders rank's stripes and its buffers hold them
+ * one after the other in ascending order (16 pixel rows per tile row).  swr_set_band returns to a contiguous band / the whole frame. */
+int  swr_set_band_interleaved(swr_context* ctx, int rank, int world, int stripe_tile_rows);
 /* use caller-provided device memory (e.g. a torch tensor that RCCL will gather) for the band's
  * colour (float4 per pixel) and depth (float per pixel); NULL returns to internal storage.  Draws recorded before the
  * call are launched against the buffers bound before it; the call itself does not wait for the GPU. */

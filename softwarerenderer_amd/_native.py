@@ -62,7 +62,7 @@ class Profile(C.Structure):
 
 # every symbol include/swr.h declares; tests/test_abi.py checks the library exports all of them
 EXPORTS = [
-    "swr_abi_version", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band",
+    "swr_abi_version", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved",
     "swr_bind_framebuffer", "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel",
     "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_host_register", "swr_host_unregister", "swr_upload", "swr_color_device_ptr",
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter", "swr_texture_sample",
@@ -95,6 +95,7 @@ def load(name: str = None) -> C.CDLL:
         "swr_destroy": (None, [P]),
         "swr_resize": (I, [P, I, I]),
         "swr_set_band": (I, [P, I, I]),
+        "swr_set_band_interleaved": (I, [P, I, I, I]),
         "swr_bind_framebuffer": (I, [P, P, P]),
         "swr_set_stream": (I, [P, P]),
         "swr_clear_color": (I, [P, fp]),

@@ -91,6 +91,8 @@ struct swr_context {
     bool band_set = false;
     int band_first = 0, band_count = 0;       // as requested by swr_set_band
     int band_ty0 = 0, band_ty1 = 0;           // effective
+    int il_k = 0, il_world = 1, il_rank = 0;  // swr_set_band_interleaved: stripes of il_k tile rows, stripe s belongs to rank s % il_world
+    int band_tile_rows = 0;                   // tile rows this context stores (contiguous band or stripes)
     float4* color = nullptr;                  // band storage in use (own or external)
     float* depth = nullptr;
     DevBuf own_color, own_depth;
@@ -179,21 +181,42 @@ void slot_submit(swr_context* c) {            // call after the batch's last lau
     c->slot_next++;
 }
 
-int band_y0(const swr_context* c) { return c->band_ty0 * SWR_TILE; }
+BandMap host_band_map(const swr_context* c) {
+    BandMap b; b.ty0 = c->band_ty0; b.ty1 = c->band_ty1; b.il_k = c->il_k; b.il_world = c->il_world; b.il_rank = c->il_rank;
+    return b;
+}
+int band_y0(const swr_context* c) { return c->band_ty0 * SWR_TILE; }     // contiguous band only
+// pixel rows stored: the band's tile rows, 16 pixel rows each, the frame's last tile row possibly partial
 int band_rows(const swr_context* c) {
-    int y1 = std::min(c->H, c->band_ty1 * SWR_TILE);
-    return std::max(0, y1 - band_y0(c));
+    if (c->band_tile_rows <= 0) return 0;
+    const int last_global = band_global_row(host_band_map(c), c->band_tile_rows - 1);
+    const int last_rows = std::min(SWR_TILE, c->H - last_global * SWR_TILE);
+    return (c->band_tile_rows - 1) * SWR_TILE + std::max(0, last_rows);
+}
+// row of pixel row y in the band's buffers, -1 if the band does not hold it
+int band_local_pixel_row(const swr_context* c, int y) {
+    if (y < 0 || y >= c->H) return -1;
+    const int lr = band_local_row(host_band_map(c), y / SWR_TILE);
+    return lr < 0 ? -1 : lr * SWR_TILE + y % SWR_TILE;
 }
 size_t band_pixels(const swr_context* c) { return (size_t)std::max(0, c->W) * (size_t)band_rows(c); }
 
 int apply_geometry(swr_context* c) {
     c->tiles_x = c->W > 0 ? (c->W + SWR_TILE - 1) / SWR_TILE : 0;     // Rasterizer.cs:76-77
     c->tiles_y = c->H > 0 ? (c->H + SWR_TILE - 1) / SWR_TILE : 0;
-    if (c->band_set) {
-        c->band_ty0 = std::min(std::max(c->band_first, 0), c->tiles_y);
-        c->band_ty1 = std::min(c->band_ty0 + std::max(c->band_count, 0), c->tiles_y);
+    if (c->il_k > 0) {
+        c->band_ty0 = 0; c->band_ty1 = c->tiles_y;                     // ownership is decided row by row (BandMap)
+        int rows = 0;
+        for (int ty = 0; ty < c->tiles_y; ++ty) rows += band_local_row(host_band_map(c), ty) >= 0 ? 1 : 0;
+        c->band_tile_rows = rows;
     } else {
-        c->band_ty0 = 0; c->band_ty1 = c->tiles_y;
+        if (c->band_set) {
+            c->band_ty0 = std::min(std::max(c->band_first, 0), c->tiles_y);
+            c->band_ty1 = std::min(c->band_ty0 + std::max(c->band_count, 0), c->tiles_y);
+        } else {
+            c->band_ty0 = 0; c->band_ty1 = c->tiles_y;
+        }
+        c->band_tile_rows = c->band_ty1 - c->band_ty0;
     }
     size_t n = band_pixels(c);
     if (c->ext_color) {
@@ -212,6 +235,7 @@ FrameParams frame_params(const swr_context* c) {
     fp.width = c->W; fp.height = c->H; fp.tiles_x = c->tiles_x; fp.tiles_y = c->tiles_y;
     fp.band_ty0 = c->band_ty0; fp.band_ty1 = c->band_ty1;
     fp.band_y0 = band_y0(c); fp.band_rows = band_rows(c);
+    fp.il_k = c->il_k; fp.il_world = c->il_world; fp.il_rank = c->il_rank; fp.band_tile_rows = c->band_tile_rows;
     fp.near_clip = c->near_clip;
     return fp;
 }
@@ -317,6 +341,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     ba.spt = b.wireframe ? 6u : 2u;
     ba.width = c->W; ba.height = c->H;
     ba.tiles_x = c->tiles_x; ba.band_ty0 = c->band_ty0; ba.band_ty1 = c->band_ty1;
+    ba.band = host_band_map(c);
     ba.tile_count = c->d_tile_count.as<uint32_t>();
     ba.tile_start = c->d_tile_start.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
@@ -331,7 +356,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
 }
 
 int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode) {
-    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
     const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
@@ -417,7 +442,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     }
     {
         ScopedSpan sp(c, ST_SORT);
-        const int band_tiles_y = c->band_ty1 - c->band_ty0;
+        const int band_tiles_y = c->band_tile_rows;
         const unsigned ob = (unsigned)(((c->tiles_x + 15) / 16) * ((band_tiles_y + 15) / 16));
         hipLaunchKernelGGL(k_tile_hist, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
                            (const uint32_t*)c->d_tile_count.as<uint32_t>(), c->tiles_x, band_tiles_y, order_hist, ctrl);
@@ -502,7 +527,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if (V + 4 * T >= 0xffffffffull || spt * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
-    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)(c->band_ty1 - c->band_ty0);
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     // the per-tile scan (k_scan_sums / k_scan_apply) holds 1024 block sums of 1024 tiles each
     if (n_tiles > (1u << 20))
         return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^20 tiles in one band (a target beyond 16384 x 16384): render it in tile-row bands (swr_set_band)");
@@ -672,7 +697,7 @@ int ensure_bounds(swr_context* c, swr_mesh* m) {
 // two pixels for the viewport arithmetic and the floor / ceil of the pixel bbox.  With large cancelling translations
 // that bound exceeds any fixed margin -- then the draw is simply kept.
 static bool band_rejects(const swr_context* c, const swr_mesh* m, const float* model, const float* view, const float* proj) {
-    if (!m->has_box || (c->band_ty0 <= 0 && c->band_ty1 >= c->tiles_y)) return false;
+    if (!m->has_box || c->il_k > 0 || (c->band_ty0 <= 0 && c->band_ty1 >= c->tiles_y)) return false;    // stripes: every rank sees the whole frame
     double mv[16], M[16], amv[16], A[16];
     for (int r = 0; r < 4; ++r)
         for (int k = 0; k < 4; ++k) {
@@ -783,7 +808,7 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
 }
 
 bool in_band(const swr_context* c, int x, int y) {
-    return x >= 0 && x < c->W && y >= band_y0(c) && y < band_y0(c) + band_rows(c);
+    return x >= 0 && x < c->W && band_local_pixel_row(c, y) >= 0;
 }
 
 }  // namespace
@@ -873,8 +898,21 @@ int swr_set_band(swr_context* c, int first_tile_row, int n_tile_rows) {
     int rc = flush_locked(c);
     if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
+    c->il_k = 0; c->il_world = 1; c->il_rank = 0;
     if (first_tile_row < 0 || n_tile_rows < 0) { c->band_set = false; }
     else { c->band_set = true; c->band_first = first_tile_row; c->band_count = n_tile_rows; }
+    c->tile_stats_tiles = 0;
+    return apply_geometry(c);
+}
+
+int swr_set_band_interleaved(swr_context* c, int rank, int world, int stripe_tile_rows) {
+    SWR_ENTER(c);
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    if (world < 1 || rank < 0 || rank >= world || stripe_tile_rows < 1) return fail(c, SWR_ERR_INVALID_ARG, "bad interleaved band arguments");
+    c->band_set = false;
+    c->il_k = stripe_tile_rows; c->il_world = world; c->il_rank = rank;
     c->tile_stats_tiles = 0;
     return apply_geometry(c);
 }
@@ -1031,7 +1069,7 @@ int swr_get_pixel(swr_context* c, int x, int y, float rgba[4]) {
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    SWR_HIP(c, hipMemcpyAsync(rgba, c->color + (size_t)(y - band_y0(c)) * c->W + x, 16, hipMemcpyDeviceToHost, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(rgba, c->color + (size_t)band_local_pixel_row(c, y) * c->W + x, 16, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
 }
 int swr_set_pixel(swr_context* c, int x, int y, const float rgba[4]) {
@@ -1040,7 +1078,7 @@ int swr_set_pixel(swr_context* c, int x, int y, const float rgba[4]) {
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    SWR_HIP(c, hipMemcpyAsync(c->color + (size_t)(y - band_y0(c)) * c->W + x, rgba, 16, hipMemcpyHostToDevice, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(c->color + (size_t)band_local_pixel_row(c, y) * c->W + x, rgba, 16, hipMemcpyHostToDevice, c->stream));
     return sync_locked(c);
 }
 int swr_get_depth(swr_context* c, int x, int y, float* d) {
@@ -1050,7 +1088,7 @@ int swr_get_depth(swr_context* c, int x, int y, float* d) {
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    SWR_HIP(c, hipMemcpyAsync(d, c->depth + (size_t)(y - band_y0(c)) * c->W + x, 4, hipMemcpyDeviceToHost, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(d, c->depth + (size_t)band_local_pixel_row(c, y) * c->W + x, 4, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
 }
 int swr_set_depth(swr_context* c, int x, int y, float d) {
@@ -1058,7 +1096,7 @@ int swr_set_depth(swr_context* c, int x, int y, float d) {
     if (!in_band(c, x, y)) return SWR_OK;
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    SWR_HIP(c, hipMemcpyAsync(c->depth + (size_t)(y - band_y0(c)) * c->W + x, &d, 4, hipMemcpyHostToDevice, c->stream));
+    SWR_HIP(c, hipMemcpyAsync(c->depth + (size_t)band_local_pixel_row(c, y) * c->W + x, &d, 4, hipMemcpyHostToDevice, c->stream));
     return sync_locked(c);
 }
 

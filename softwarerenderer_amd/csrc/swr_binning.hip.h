@@ -24,7 +24,8 @@ struct BinArgs {
     uint32_t spt;                        // slots per thread = slots per triangle (2 filled, 6 wireframe): the odd
                                          // fan slots are almost always empty, so a thread walks its triangle's slots
     int tiles_x;
-    int band_ty0, band_ty1;
+    int band_ty0, band_ty1;              // tile rows binned: the contiguous band, or [0, tiles_y) with `band` deciding row by row
+    BandMap band;                        // tile-row ownership (contiguous band or interleaved stripes)
     int width, height;
     uint32_t* __restrict__ tile_count;   // COUNT: incremented; FILL: used as cursor (zeroed again before)
     const uint32_t* __restrict__ tile_start;
@@ -168,8 +169,8 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
                 const bool b_line = __shfl((int)sd.is_line, src) != 0;
                 if (lane < s_nt) {
                     const int ty = s_tminy + lane / s_nx, tx = s_tminx + lane % s_nx;
-                    want[j] = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
-                    tile[j] = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                    want[j] = band_local_row(a.band, ty) >= 0 && pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
+                    tile[j] = (uint32_t)(band_local_row(a.band, ty) * a.tiles_x + tx);
                 }
                 if (want[j]) {
                     if (FILL) base[j] = atomicAdd(&a.tile_count[tile[j]], 1u);
@@ -206,10 +207,10 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
             int ty = 0, tx = 0;
             if (want) {
                 ty = s_tminy + i / s_nx; tx = s_tminx + i % s_nx;
-                want = pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
+                want = band_local_row(a.band, ty) >= 0 && pair_may_cover(bsx, bsy, bminX, bmaxX, bminY, bmaxY, tx, ty, a.width, a.height, b_line);
             }
             if (want) {
-                const uint32_t tile = (uint32_t)((ty - a.band_ty0) * a.tiles_x + tx);
+                const uint32_t tile = (uint32_t)(band_local_row(a.band, ty) * a.tiles_x + tx);
                 if (FILL) {
                     const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
                     if (at < a.list_capacity) a.tile_list[at] = s_slot;
@@ -260,11 +261,11 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
                 bool want;
                 if (FILL) want = ((wmask >> i) & 1u) != 0u;
                 else {
-                    want = pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
+                    want = band_local_row(a.band, wty) >= 0 && pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
                     wmask |= want ? (1u << i) : 0u;
                 }
                 if (want) {
-                    const uint32_t tile = (uint32_t)((wty - a.band_ty0) * a.tiles_x + wtx);
+                    const uint32_t tile = (uint32_t)(band_local_row(a.band, wty) * a.tiles_x + wtx);
                     uint32_t e = (tile * 0x9E3779B1u) >> (32 - SWR_BIN_TABLE_LOG2);
                     bool placed = false;
                     for (int probe = 0; probe < 16; ++probe) {

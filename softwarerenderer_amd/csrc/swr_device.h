@@ -97,11 +97,32 @@ struct Ctrl {
 struct FrameParams {
     int width, height;          // full frame
     int tiles_x, tiles_y;       // full frame, in 16x16 tiles
-    int band_ty0, band_ty1;     // this context renders tile rows [band_ty0, band_ty1)
-    int band_y0;                // = band_ty0 * 16: first pixel row stored in the buffers
+    int band_ty0, band_ty1;     // this context renders tile rows [band_ty0, band_ty1) ...
+    int band_y0;                // = band_ty0 * 16: first pixel row stored in the buffers (contiguous band)
     int band_rows;              // pixel rows stored
+    int il_k, il_world, il_rank;   // ... or, when il_k > 0, the stripes of il_k tile rows whose stripe number s has s % il_world == il_rank
+    int band_tile_rows;         // tile rows stored (either form); the buffers hold them in ascending order, 16 pixel rows each
     float near_clip;
 };
+
+// Tile-row ownership of a context (multi-GPU): a contiguous band, or interleaved stripes (load balance for clustered
+// scenes).  local row = position of the tile row in this context's buffers, -1 = not ours.
+struct BandMap { int ty0, ty1, il_k, il_world, il_rank; };
+__host__ __device__ __forceinline__ int band_local_row(const BandMap& b, int ty) {
+    if (b.il_k <= 0) return (ty >= b.ty0 && ty < b.ty1) ? ty - b.ty0 : -1;
+    const int stripe = ty / b.il_k;
+    if (stripe % b.il_world != b.il_rank) return -1;
+    return (stripe / b.il_world) * b.il_k + (ty - stripe * b.il_k);
+}
+__host__ __device__ __forceinline__ int band_global_row(const BandMap& b, int local) {
+    if (b.il_k <= 0) return b.ty0 + local;
+    const int ls = local / b.il_k;
+    return (ls * b.il_world + b.il_rank) * b.il_k + (local - ls * b.il_k);
+}
+__host__ __device__ __forceinline__ BandMap band_map(const FrameParams& fp) {
+    BandMap b; b.ty0 = fp.band_ty0; b.ty1 = fp.band_ty1; b.il_k = fp.il_k; b.il_world = fp.il_world; b.il_rank = fp.il_rank;
+    return b;
+}
 
 // ---------------------------------------------------------------- .NET scalar semantics ----
 __device__ __forceinline__ bool is_neg_bits(float f) { return (__float_as_uint(f) >> 31) != 0u; }

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         int area = 0;
         if (p_own < n_pairs) {
             const uint32_t slot = a.tile_list[p_own], tile = a.pair_tile[p_own];
-            const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = a.fp.band_ty0 + (int)(tile / (uint32_t)a.fp.tiles_x);
+            const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
             const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
             const float4 r3 = reinterpret_cast<const float4*>(a.recs + slot)[3];
             const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     if (p < n_pairs) {
         const uint32_t slot = a.tile_list[p];
         const uint32_t tile = a.pair_tile[p];
-        const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = a.fp.band_ty0 + (int)(tile / (uint32_t)a.fp.tiles_x);
+        const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
         const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
@@ -367,8 +367,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         tile_o = a.tile_order[j];
     }
     const int tx = (int)(tile_o % (uint32_t)a.fp.tiles_x), ty_local = (int)(tile_o / (uint32_t)a.fp.tiles_x);
-    const int ty = a.fp.band_ty0 + ty_local;
-    if (tx >= a.fp.tiles_x || ty >= a.fp.band_ty1) return;
+    if (tx >= a.fp.tiles_x || ty_local >= a.fp.band_tile_rows) return;
+    const int ty = band_global_row(band_map(a.fp), ty_local);
     const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
     const uint32_t n = a.tile_count[tile];
     if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const int p = rr * 64 + lane;
         const int gx = x0 + (p & 15), gy = y0 + (p >> 4);
         const bool inb = gx < W && gy < H;
-        const size_t gi = (size_t)(gy - a.fp.band_y0) * (size_t)W + (size_t)gx;
+        const size_t gi = (size_t)(ty_local * SWR_TILE + (p >> 4)) * (size_t)W + (size_t)gx;     // the band's buffers hold its tile rows consecutively
         float4 c;
         if (a.clear_color_on) c = make_float4(a.clear_rgba[0], a.clear_rgba[1], a.clear_rgba[2], a.clear_rgba[3]);
         else c = inb ? a.color[gi] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const int p = rr * 64 + lane;
         const int gx = x0 + (p & 15), gy = y0 + (p >> 4);
         if (gx < W && gy < H) {
-            const size_t gi = (size_t)(gy - a.fp.band_y0) * (size_t)W + (size_t)gx;
+            const size_t gi = (size_t)(ty_local * SWR_TILE + (p >> 4)) * (size_t)W + (size_t)gx;     // the band's buffers hold its tile rows consecutively
             a.color[gi] = L.col[p];
             a.depth[gi] = L.z[p];
         }

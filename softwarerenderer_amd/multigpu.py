@@ -37,6 +37,41 @@ def band_partition(height: int, world_size: int) -> List[Tuple[int, int]]:
     return out
 
 
+def stripe_rows(height: int, world_size: int, stripe_tile_rows: int) -> List[np.ndarray]:
+    """Interleaved variant (swr_set_band_interleaved): the tile rows are cut into stripes of `stripe_tile_rows` rows, stripe s
+    belongs to rank s % world_size.  Returns, per rank, the frame's pixel rows that rank stores, in storage order -- i.e.
+    `frame[rows[r]] = band_r[:len(rows[r])]` reassembles the frame (assemble_stripes)."""
+    n = tile_rows(height)
+    out = [[] for _ in range(world_size)]
+    for ty in range(n):
+        r = (ty // stripe_tile_rows) % world_size
+        out[r].extend(range(ty * TILE, min(height, (ty + 1) * TILE)))
+    return [np.asarray(o, dtype=np.int64) for o in out]
+
+
+def assemble_stripes(bands, height: int, world_size: int, stripe_tile_rows: int, frame=None):
+    """Scatter per-rank stripe buffers (numpy arrays or torch tensors, rows beyond a rank's own count are padding) into the
+    (height, ...) frame: one indexed row copy per rank."""
+    rows = stripe_rows(height, world_size, stripe_tile_rows)
+    is_torch = not isinstance(bands[0], np.ndarray)
+    if frame is None:
+        shape = (height,) + tuple(bands[0].shape[1:])
+        if is_torch:
+            import torch
+            frame = torch.empty(shape, dtype=bands[0].dtype, device=bands[0].device)
+        else:
+            frame = np.empty(shape, dtype=bands[0].dtype)
+    for r, idx in enumerate(rows):
+        if len(idx) == 0:
+            continue
+        if is_torch:
+            import torch
+            frame.index_copy_(0, torch.as_tensor(idx, device=frame.device), bands[r][:len(idx)])
+        else:
+            frame[idx] = bands[r][:len(idx)]
+    return frame
+
+
 def band_pixel_rows(height: int, band: Tuple[int, int]) -> Tuple[int, int]:
     """(first pixel row, number of pixel rows) stored by a band."""
     y0 = band[0] * TILE

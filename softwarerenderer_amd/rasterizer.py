@@ -266,8 +266,11 @@ class MainWindow:
             return
         lib, ctx = self._dev._lib, self._dev._ctx
         self._dev._ck(lib.swr_resize(ctx, self.RenderWidth, self.RenderHeight))
-        b = self._band if self._band is not None else (-1, -1)
-        self._dev._ck(lib.swr_set_band(ctx, b[0], b[1]))
+        if self._band is not None and len(self._band) == 3:
+            self._dev._ck(lib.swr_set_band_interleaved(ctx, *self._band))
+        else:
+            b = self._band if self._band is not None else (-1, -1)
+            self._dev._ck(lib.swr_set_band(ctx, b[0], b[1]))
         cb = self._bound if self._bound is not None else (None, None)
         self._dev._ck(lib.swr_bind_framebuffer(ctx, C.c_void_p(cb[0]) if cb[0] else None, C.c_void_p(cb[1]) if cb[1] else None))
         self._dev._active_window = self
@@ -282,10 +285,20 @@ class MainWindow:
         self._dev._active_window = None
         self._activate()
 
+    def SetBandInterleaved(self, rank: int, world: int, stripe_tile_rows: int):
+        """Interleaved stripes instead of one contiguous band: stripe s (stripe_tile_rows tile rows) belongs to rank s % world;
+        the window then holds this rank's stripes one after the other (multigpu.stripe_rows gives their frame rows)."""
+        self._band = (int(rank), int(world), int(stripe_tile_rows))
+        self._dev._active_window = None
+        self._activate()
+
     def band_pixel_rows(self):
         tiles_y = (self.RenderHeight + 15) // 16
         if self._band is None:
             return 0, max(self.RenderHeight, 0)
+        if len(self._band) == 3:
+            from . import multigpu
+            return 0, len(multigpu.stripe_rows(self.RenderHeight, self._band[1], self._band[2])[self._band[0]])
         t0 = min(max(self._band[0], 0), tiles_y)
         t1 = min(t0 + max(self._band[1], 0), tiles_y)
         y0, y1 = t0 * 16, min(self.RenderHeight, t1 * 16)

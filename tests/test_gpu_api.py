@@ -448,3 +448,32 @@ def test_band_union_with_large_cancelling_translations(device):
             cols.append(c); deps.append(d)
         assert np.array_equal(np.concatenate(deps).view(np.uint32), d0.view(np.uint32))
         assert np.array_equal(np.concatenate(cols).view(np.uint32), c0.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,k", [(2, 1), (3, 2), (4, 3)])
+def test_interleaved_stripes_union_is_the_single_gpu_frame(device, world, k):
+    """swr_set_band_interleaved: stripes of k tile rows dealt round-robin to `world` ranks (load balance for clustered scenes,
+    SURVEY.md section 8e).  Each rank's window renders its stripes; scattering them back gives the frame of the oracle."""
+    scene = scenes.cfg3(300, 270, (3, 3), (20, 14), tex_size=64, seed=8)
+    rc, rd, ost = render_oracle(scene)
+    cols, deps, frag = [], [], 0
+    for rank in range(world):
+        win = MainWindow(device, scene.width, scene.height)
+        win.SetBandInterleaved(rank, world, k)
+        device.reset_stats()
+        r = scenes.SceneRenderer(device, scene, window=win)
+        c, d = r.render()
+        frag += device.stats()["fragments_written"]
+        r.close()
+        cols.append(c); deps.append(d)
+        # accessors address the interleaved layout too
+        rows = multigpu.stripe_rows(scene.height, world, k)[rank]
+        y = int(rows[len(rows) // 2])
+        assert np.array_equal(win.GetPixel(5, y), c[len(rows) // 2, 5])
+        other = next(yy for yy in range(scene.height) if yy not in set(rows.tolist()))
+        assert win.GetDepth(5, other) == MINVAL and not win.GetPixel(5, other).any()          # out of band = out of bounds
+    MainWindow(device, scene.width, scene.height).SetBand(-1, -1)
+    c = multigpu.assemble_stripes(cols, scene.height, world, k)
+    d = multigpu.assemble_stripes(deps, scene.height, world, k)
+    assert_frame_parity(c, d, rc, rd, 1, f"stripes world={world} k={k}")
+    assert frag == ost["fragments_written"]
