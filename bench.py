@@ -59,10 +59,17 @@ def main():
                          "(Vector4 -> Vector3 flatten, 12 B/pixel) by an RCCL gather, rgba32f = the raw colour buffer (16 B/pixel) "
                          "by an RCCL gather, p2p = the rgb32f payload stored by every rank's flatten kernel straight into rank 0's "
                          "frame through a peer-mapped (IPC) pointer over xGMI: no collective in the data path, one barrier per frame")
+    ap.add_argument("--stripes", type=int, default=0,
+                    help="N>1: instead of one contiguous band per rank, interleave stripes of this many tile rows round-robin over "
+                         "the ranks (swr_set_band_interleaved; load balance for clustered scenes).  RCCL gather modes only.")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; gloo (control plane only, needs --gather p2p) rehearses the N>1 path with "
                          "several ranks on ONE GPU (SWR_BENCH_ONE_DEVICE=1), which RCCL refuses")
+    ap.add_argument("--print-src-hash", action="store_true", help="print the kernel-source hash (tools/profile_round.sh) and exit")
     args = ap.parse_args()
+    if args.print_src_hash:
+        print(kernel_source_hash())
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,10 +119,17 @@ def main():
     if world > 1:
         band = multigpu.band_partition(H, world)[rank]
         rows = multigpu.max_band_rows(H, world)
+        if args.stripes > 0:
+            if args.gather == "p2p":
+                raise SystemExit("--stripes needs an RCCL gather mode (a stripe set is not one contiguous block of rank 0's frame)")
+            rows = max(len(r) for r in multigpu.stripe_rows(H, world, args.stripes))
         # two band buffers: the colour gather of frame i (RCCL, xGMI) overlaps the rendering of frame i+1
         color_t = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
         depth_t = [torch.zeros((rows, W), dtype=torch.float32, device="cuda") for _ in range(2 if overlap else 1)]
-        window.SetBand(*band)
+        if args.stripes > 0:
+            window.SetBandInterleaved(rank, world, args.stripes)
+        else:
+            window.SetBand(*band)
         window.BindFramebuffer(color_t[0].data_ptr(), depth_t[0].data_ptr())
     p2p = world > 1 and args.gather == "p2p"
     rgb = world > 1 and args.gather in ("rgb32f", "p2p")
@@ -154,7 +168,16 @@ def main():
             return
         if rgb:
             window.FlattenToAsync(rgb_t[k].data_ptr())     # present payload: Vector4 -> Vector3 on the GPU (MainWindow.cs:234-240)
-        multigpu.gather_bands(rgb_t[k] if rgb else color_t[k], H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+        payload = rgb_t[k] if rgb else color_t[k]
+        if args.stripes > 0:
+            # stripes: gather the per-rank stripe buffers, then one indexed row copy per rank scatters them into the frame
+            if rank == 0 and state.get("stripe_bufs") is None:
+                state["stripe_bufs"] = [torch.empty_like(payload) for _ in range(world)]
+            dist.gather(payload, gather_list=state.get("stripe_bufs") if rank == 0 else None, dst=0)
+            if rank == 0:
+                multigpu.assemble_stripes(state["stripe_bufs"], H, world, args.stripes, frame=frame_t)
+            return
+        multigpu.gather_bands(payload, H, W, rank, world, dst=0, frame=frame_t, dist=dist)
 
     def validate_previous():
         """The stream has drained: let the backend look at its optimistic batches.  If one had not fitted (never in steady
@@ -299,13 +322,14 @@ def main():
             written_local = st["fragments_written"] / args.steps
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
             frame_bytes = (W * H if world == 1 else color_t[0].shape[0] * W) * 20.0
+            traffic, traffic_detail = pmc_traffic(args.config, world)
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_raster_c",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "frac_of_measured_copy_peak": round(achieved / HBM_MEASURED_GBS, 5),
-                "traffic": pmc_traffic(args.config, world),
-                "traffic_unit": "GB per launch (PMC FETCH_SIZE raw + WRITE_SIZE; algorithmic = written fragments x 20 B)",
+                "traffic": traffic, "traffic_detail": traffic_detail,
+                "traffic_unit": "GB per launch = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this build (null: none for this build); algorithmic = written fragments x 20 B",
                 "algorithmic_gb_per_launch": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / 1e9, 4),
                 "kernel_ms": round(raster_ms, 4),
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -323,34 +347,52 @@ def main():
         dist.destroy_process_group()
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources the library is built from: ties a committed PMC pass to the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "softwarerenderer_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join("..", "..", "include", "swr.h")]:
+        path = os.path.join(d, f)
+        if os.path.isfile(path):
+            h.update(os.path.basename(f).encode()); h.update(open(path, "rb").read())
+    return h.hexdigest()
+
+
 def pmc_traffic(config, world):
-    """HBM bytes per k_raster launch from the committed PMC passes of this same command (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside bench.py).  Read side taken raw (lower bound, see the
-    file's provenance note); null when no pass exists for this configuration."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world != 1 or not os.path.exists(path):
-        return None
-    t = json.load(open(path)).get(config)
-    if not t:
-        return None
-    return round((t["fetch_kib_raw"] + t["write_kib"]) * 1024 / 1e9, 4)      # GB per launch
+    """HBM-side bytes per k_raster_c launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE in separate passes; they cannot run inside bench.py).  Corrected as MI355X_MICROARCH.md prescribes: the
+    counters are KiB, and gfx950's FETCH_SIZE tallies a 128-B request as 64 B, so the read side is doubled (an upper bound for this
+    kernel's mix of 16-B gathers and 4-B texel gathers; the raw figure rides along).  The pass is only valid for the build it
+    measured: the JSON carries a hash of the kernel sources, and a different build reports null instead of a stale number."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if world != 1 or not cands:
+        return None, None
+    j = json.load(open(cands[-1]))
+    t = j.get(config)
+    if not t or j.get("csrc_sha256") != kernel_source_hash():
+        return None, {"stale": os.path.basename(cands[-1])} if t else None
+    raw = (t["fetch_kib_raw"] + t["write_kib"]) * 1024 / 1e9
+    cor = (2.0 * t["fetch_kib_raw"] + t["write_kib"]) * 1024 / 1e9
+    return round(cor, 4), {"file": os.path.basename(cands[-1]), "fetch_raw_gb": round(t["fetch_kib_raw"] * 1024 / 1e9, 4),
+                           "write_gb": round(t["write_kib"] * 1024 / 1e9, 4), "raw_sum_gb": round(raw, 4)}
 
 
 def cpu_baseline(scene, renderer, np):
-    """The C restatement of the reference (oracle/, kind "port") timed on this box's host cores on the
-    SAME frame: all-core threaded variant (per-tile locks like Rasterizer.cs:478) for `value`, plus one
-    serial frame that is also compared word for word with the GPU frame."""
+    """The C restatement of the reference (oracle/, kind "port") timed on this box's host cores on the SAME frame:
+    the threaded variant (persistent pool, a mutex per tile like Rasterizer.cs:478, Parallel.For-style chunks) at several
+    thread counts -- 1 warm-up + 5 timed frames each, median -- with the fastest as `value` / `cores`, plus ONE serial frame
+    (the oracle of record: `serial_value`), which is also compared word for word with the GPU frame.  Bounded: ~20 s."""
     from oracle.binding import OracleRenderer
     ncpu = os.cpu_count() or 1
-    # the per-tile-lock structure of the reference stops scaling long before 256 threads on this scene: time a few
-    # thread counts (bounded) and report the fastest, with the thread count actually used as `cores`
-    best = None
+    tried, best = {}, None
     budget_t0 = time.perf_counter()
-    for threads in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for threads in sorted({ncpu, max(1, ncpu // 2), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         o = OracleRenderer(scene.width, scene.height, threads=threads)
-        o.render_scene(scene)                      # warm-up
+        o.render_scene(scene)                      # warm-up (also starts the pool)
         times = []
-        for _ in range(3):
+        for _ in range(5):
             o.reset_stats()
             t0 = time.perf_counter()
             o.render_scene(scene)
@@ -358,15 +400,17 @@ def cpu_baseline(scene, renderer, np):
         st = o.stats()
         o.close()
         t = sorted(times)[len(times) // 2]
+        tried[str(threads)] = round(st["fragments_tested"] / t / 1e6, 1)
         if best is None or t < best[0]:
             best = (t, threads, st, len(times))
-        if time.perf_counter() - budget_t0 > 15.0:
+        if time.perf_counter() - budget_t0 > 12.0:
             break
     t, cores, st, nrep = best
     res = {"value": round(st["fragments_tested"] / t / 1e6, 3), "unit": "Mfragments/s", "cores": cores, "kind": "port",
-           "sample": f"the whole {scene.name} frame, median of {nrep} frames after 1 warm-up, fastest of several thread counts "
-                     f"(host has {ncpu} hardware threads), threaded C restatement of Rasterizer.cs (oracle/swr_oracle.c)",
-           "ms_per_frame": round(t * 1e3, 2)}
+           "sample": f"the whole {scene.name} frame: median of {nrep} timed frames after 1 warm-up per thread count, fastest count reported "
+                     f"(host has {ncpu} hardware threads); threaded C restatement of Rasterizer.cs (oracle/swr_oracle.c: persistent pool, "
+                     f"per-tile mutexes, far-apart triangle chunks); serial_value = one frame on 1 thread",
+           "ms_per_frame": round(t * 1e3, 2), "mfragments_per_s_by_threads": tried}
     # one serial frame = the oracle of record; doubles as a full-size parity check of the GPU frame
     o = OracleRenderer(scene.width, scene.height, threads=1)
     t0 = time.perf_counter()
@@ -375,6 +419,7 @@ def cpu_baseline(scene, renderer, np):
     sst = o.stats()
     o.close()
     res["serial_value"] = round(sst["fragments_tested"] / ts / 1e6, 3)
+    res["serial_ms_per_frame"] = round(ts * 1e3, 1)
     gc, gd = renderer.render()
     depth_exact = bool(np.array_equal(gd.view(np.uint32), rd.view(np.uint32)))
     a = gc.view(np.int32).astype(np.int64); b = rc.view(np.int32).astype(np.int64)

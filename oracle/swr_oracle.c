@@ -41,8 +41,10 @@ struct oswr_context {
     int tex_bilinear;           /* build-defined extension: bilinear instead of the reference's nearest filter */
     int n_threads;
     int tiles_x, tiles_y;       /* Rasterizer.cs:55 */
-    atomic_flag* tile_locks;    /* Rasterizer.cs:54 (monitor per tile) */
+    pthread_mutex_t* tile_locks; /* Rasterizer.cs:54 (monitor per tile): a mutex each, like the C# `lock` -- a spinning flag starves
+                                  * once there are more threads than a few tiles' worth of contention */
     oswr_stats stats;
+    struct oswr_pool* pool;     /* persistent workers (the reference's Parallel.For runs on the .NET thread pool) */
 };
 
 /* ---------- .NET scalar semantics ---------- */
@@ -165,16 +167,23 @@ void oswr_clear_depth(oswr_context* c) {                         /* MainWindow.c
     for (size_t i = 0; i < n; ++i) c->depth[i] = FLOAT_MINVALUE;
 }
 
+static void free_tile_locks(oswr_context* c) {
+    if (c->tile_locks) for (int i = 0; i < c->tiles_x * c->tiles_y; ++i) pthread_mutex_destroy(&c->tile_locks[i]);
+    free(c->tile_locks);
+    c->tile_locks = NULL;
+}
+static void pool_destroy(oswr_context* c);
+
 /* Rasterizer.InitializeTileLocks, Rasterizer.cs:69-93 */
 static int init_tile_locks(oswr_context* c, int width, int height) {
     if (width <= 0 || height <= 0) return -1;   /* C#: throws ArgumentException */
     int tx = (width + TILE_SIZE - 1) / TILE_SIZE;
     int ty = (height + TILE_SIZE - 1) / TILE_SIZE;
     if (tx == c->tiles_x && ty == c->tiles_y && c->tile_locks) return 0;
-    free(c->tile_locks);
+    free_tile_locks(c);
     c->tiles_x = tx; c->tiles_y = ty;
-    c->tile_locks = (atomic_flag*)malloc(sizeof(atomic_flag) * (size_t)tx * ty);
-    for (int i = 0; i < tx * ty; ++i) atomic_flag_clear(&c->tile_locks[i]);
+    c->tile_locks = (pthread_mutex_t*)malloc(sizeof(pthread_mutex_t) * (size_t)tx * ty);
+    for (int i = 0; i < tx * ty; ++i) pthread_mutex_init(&c->tile_locks[i], NULL);
     return 0;
 }
 
@@ -185,7 +194,7 @@ int oswr_resize(oswr_context* c, int width, int height) {        /* MainWindow.c
     size_t n = (size_t)width * height;
     c->color = (float*)calloc(n ? n : 1, 16);
     c->depth = (float*)calloc(n ? n : 1, 4);
-    free(c->tile_locks); c->tile_locks = NULL; c->tiles_x = c->tiles_y = 0;
+    free_tile_locks(c); c->tiles_x = c->tiles_y = 0;
     return (c->color && c->depth) ? 0 : -2;
 }
 oswr_context* oswr_create(int width, int height) {
@@ -198,12 +207,13 @@ oswr_context* oswr_create(int width, int height) {
 }
 void oswr_destroy(oswr_context* c) {
     if (!c) return;
-    free(c->color); free(c->depth); free(c->tile_locks); free(c);
+    pool_destroy(c);
+    free(c->color); free(c->depth); free_tile_locks(c); free(c);
 }
 void oswr_set_state(oswr_context* c, float near_clip, float far_clip, int debug_mode) {
     c->near_clip = near_clip; c->far_clip = far_clip; c->debug_mode = debug_mode;
 }
-void oswr_set_threads(oswr_context* c, int n) { c->n_threads = n < 1 ? 1 : n; }
+void oswr_set_threads(oswr_context* c, int n) { n = n < 1 ? 1 : n; if (n != c->n_threads) pool_destroy(c); c->n_threads = n; }
 float* oswr_color_buffer(oswr_context* c) { return c->color; }
 float* oswr_depth_buffer(oswr_context* c) { return c->depth; }
 int oswr_width(oswr_context* c) { return c->width; }
@@ -476,10 +486,10 @@ typedef struct {
 } draw_state;
 
 static inline void tile_lock(draw_state* ds, int idx) {
-    if (ds->threaded) while (atomic_flag_test_and_set_explicit(&ds->ctx->tile_locks[idx], memory_order_acquire)) { }
+    if (ds->threaded) pthread_mutex_lock(&ds->ctx->tile_locks[idx]);
 }
 static inline void tile_unlock(draw_state* ds, int idx) {
-    if (ds->threaded) atomic_flag_clear_explicit(&ds->ctx->tile_locks[idx], memory_order_release);
+    if (ds->threaded) pthread_mutex_unlock(&ds->ctx->tile_locks[idx]);
 }
 
 /* fragment tail shared by RasterizeTriangle and DrawLine; alpha_rule: 0 => W > 0 (:511), 1 => W != 0 (:325)
@@ -704,24 +714,87 @@ static void process_triangle(draw_state* ds, const oswr_vertex_input* vertices, 
     }
 }
 
+/* One RenderMesh call = one job for the persistent pool (the reference: Parallel.For over the triangles of the mesh on the
+ * .NET thread pool, Rasterizer.cs:200).  Triangles are handed out in chunks; consecutive grabs take chunks that lie far apart in
+ * the mesh (chunk j -> (j % lanes) * per_lane + j / lanes), because neighbouring triangles share tiles and would queue on
+ * the same tile locks. */
+#define OSWR_CHUNK 64
 typedef struct {
-    draw_state ds; oswr_stats stats;
+    draw_state ds;
     const oswr_vertex_input* vertices; const uint16_t* indices; int n_tris;
     const float *model, *view, *proj;
-    atomic_int* next;
-} worker_arg;
+    atomic_int next;
+    int n_chunks, lanes, per_lane;
+} oswr_job;
 
-static void* worker_main(void* p) {
-    worker_arg* a = (worker_arg*)p;
-    a->ds.stats = &a->stats;
+typedef struct oswr_pool {
+    int n; pthread_t* th; oswr_stats* stats;
+    pthread_mutex_t mu; pthread_cond_t cv_job, cv_done;
+    unsigned gen; int running, shutdown;
+    oswr_job job;
+    oswr_context* ctx;
+} oswr_pool;
+
+typedef struct { oswr_pool* pool; int id; } pool_arg;
+
+static void run_job(oswr_job* j, oswr_stats* st) {
+    draw_state ds = j->ds;
+    ds.stats = st;
     for (;;) {
-        int base = atomic_fetch_add(a->next, 16);
-        if (base >= a->n_tris) break;
-        int end = imin(base + 16, a->n_tris);
+        int g = atomic_fetch_add(&j->next, 1);
+        if (g >= j->n_chunks) break;
+        int chunk = (g % j->lanes) * j->per_lane + g / j->lanes;
+        int base = chunk * OSWR_CHUNK, end = imin(base + OSWR_CHUNK, j->n_tris);       /* chunk ids past the mesh give an empty range */
         for (int i = base; i < end; ++i)
-            process_triangle(&a->ds, a->vertices, a->indices, i, a->model, a->view, a->proj);
+            process_triangle(&ds, j->vertices, j->indices, i, j->model, j->view, j->proj);
     }
-    return NULL;
+}
+
+static void* pool_main(void* p) {
+    pool_arg* pa = (pool_arg*)p;
+    oswr_pool* pool = pa->pool; int id = pa->id;
+    free(pa);
+    unsigned seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&pool->mu);
+        while (pool->gen == seen && !pool->shutdown) pthread_cond_wait(&pool->cv_job, &pool->mu);
+        if (pool->shutdown) { pthread_mutex_unlock(&pool->mu); return NULL; }
+        seen = pool->gen;
+        pthread_mutex_unlock(&pool->mu);
+        run_job(&pool->job, &pool->stats[id]);
+        pthread_mutex_lock(&pool->mu);
+        if (--pool->running == 0) pthread_cond_signal(&pool->cv_done);
+        pthread_mutex_unlock(&pool->mu);
+    }
+}
+
+static oswr_pool* pool_get(oswr_context* c) {
+    if (c->pool) return c->pool;
+    oswr_pool* pool = (oswr_pool*)calloc(1, sizeof(*pool));
+    pool->n = c->n_threads; pool->ctx = c;
+    pool->th = (pthread_t*)calloc((size_t)pool->n, sizeof(pthread_t));
+    pool->stats = (oswr_stats*)calloc((size_t)pool->n, sizeof(oswr_stats));
+    pthread_mutex_init(&pool->mu, NULL); pthread_cond_init(&pool->cv_job, NULL); pthread_cond_init(&pool->cv_done, NULL);
+    for (int t = 0; t < pool->n; ++t) {
+        pool_arg* pa = (pool_arg*)malloc(sizeof(*pa));
+        pa->pool = pool; pa->id = t;
+        pthread_create(&pool->th[t], NULL, pool_main, pa);
+    }
+    c->pool = pool;
+    return pool;
+}
+
+static void pool_destroy(oswr_context* c) {
+    oswr_pool* pool = c->pool;
+    if (!pool) return;
+    pthread_mutex_lock(&pool->mu);
+    pool->shutdown = 1;
+    pthread_cond_broadcast(&pool->cv_job);
+    pthread_mutex_unlock(&pool->mu);
+    for (int t = 0; t < pool->n; ++t) pthread_join(pool->th[t], NULL);
+    pthread_mutex_destroy(&pool->mu); pthread_cond_destroy(&pool->cv_job); pthread_cond_destroy(&pool->cv_done);
+    free(pool->th); free(pool->stats); free(pool);
+    c->pool = NULL;
 }
 
 static void stats_add(oswr_stats* d, const oswr_stats* s) {
@@ -754,18 +827,30 @@ int oswr_render_mesh(oswr_context* c,
         for (int i = 0; i < n_tris; ++i) process_triangle(&ds, vertices, indices, i, model, view, projection);
         return 0;
     }
-    int nt = c->n_threads;
-    pthread_t* th_ = (pthread_t*)malloc(sizeof(pthread_t) * nt);
-    worker_arg* args = (worker_arg*)calloc(nt, sizeof(worker_arg));
-    atomic_int next; atomic_init(&next, 0);
+    oswr_pool* pool = pool_get(c);
     ds.threaded = 1;
-    for (int t = 0; t < nt; ++t) {
-        args[t].ds = ds; args[t].vertices = vertices; args[t].indices = indices; args[t].n_tris = n_tris;
-        args[t].model = model; args[t].view = view; args[t].proj = projection; args[t].next = &next;
-        pthread_create(&th_[t], NULL, worker_main, &args[t]);
+    oswr_job* j = &pool->job;
+    j->ds = ds; j->vertices = vertices; j->indices = indices; j->n_tris = n_tris;
+    j->model = model; j->view = view; j->proj = projection;
+    atomic_store(&j->next, 0);
+    j->n_chunks = (n_tris + OSWR_CHUNK - 1) / OSWR_CHUNK;
+    j->lanes = pool->n < j->n_chunks ? pool->n : (j->n_chunks > 0 ? j->n_chunks : 1);
+    j->per_lane = (j->n_chunks + j->lanes - 1) / j->lanes;
+    /* the grab counter must cover the (lanes x per_lane) grid, which can exceed n_chunks by up to lanes - 1 slots */
+    j->n_chunks = j->n_chunks;      /* bound for the chunk id; the loop below walks lanes * per_lane grabs */
+    {
+        int grid = j->lanes * j->per_lane, real = j->n_chunks;
+        j->n_chunks = grid;                            /* grabs g in [0, grid); run_job skips chunk ids >= real via n_tris */
+        (void)real;
     }
-    for (int t = 0; t < nt; ++t) { pthread_join(th_[t], NULL); stats_add(&c->stats, &args[t].stats); }
-    free(th_); free(args);
+    memset(pool->stats, 0, sizeof(oswr_stats) * (size_t)pool->n);
+    pthread_mutex_lock(&pool->mu);
+    pool->running = pool->n;
+    pool->gen++;
+    pthread_cond_broadcast(&pool->cv_job);
+    while (pool->running > 0) pthread_cond_wait(&pool->cv_done, &pool->mu);
+    pthread_mutex_unlock(&pool->mu);
+    for (int t = 0; t < pool->n; ++t) stats_add(&c->stats, &pool->stats[t]);
     return 0;
 }
 
