@@ -640,6 +640,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
+            // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
+            const bool f_interp = PROG > SWR_PROG_FLAT_COLOR ? true : (__float_as_uint(f1.w) & SWR_FLAG_INTERP) != 0u;
 #ifdef SWR_DEBUG_COUNTERS
             int dbg_nrow = 0, dbg_ncol = 0;
 #endif
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #ifdef SWR_ABL_NOSHADE
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                        const float4 src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                        const float4 src = shade_fragment<PHONG>(cdp, f_program, f_interp,
                                                                  load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     e_d = d;
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
-                        e_src = shade_fragment<PHONG>(cdp, f_program, (dflags & SWR_FLAG_INTERP) != 0u,
+                        e_src = shade_fragment<PHONG>(cdp, f_program, f_interp,
                                                       load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output dirs (gpurun_out/...) into a small tracked summary under profiles/.
 
-usage: summarize_rocprof.py TAG STATS_DIR [PMC_FETCH_DIR] [PMC_WRITE_DIR] [BENCH_JSON]
-Writes profiles/TAG_kernel_stats.csv (verbatim rocprofv3 --stats table) and profiles/TAG_summary.md.
+usage: summarize_rocprof.py TAG STATS_DIR [PMC_FETCH_DIR] [PMC_WRITE_DIR] [BENCH_JSON] [SRC_HASH_FILE CONFIG]
+Writes profiles/TAG_kernel_stats.csv (verbatim rocprofv3 --stats table) and profiles/TAG_summary.md; with SRC_HASH_FILE
+(bench.py --print-src-hash of the build that was profiled) also profiles/<round>_traffic.json, which bench.py reads for
+`roofline.traffic` -- and ignores when the kernel sources have changed since.
 HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in
 KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of a wide coalesced stream, so the read side is reported both
 raw and doubled (k_raster's reads are scalar record loads and 4-byte texel gathers -- uncalibrated widths --
@@ -55,6 +57,20 @@ def main():
         if js:
             lines += ["", "bench.py line of the same command:", "", "```json", json.dumps(json.loads(js[-1]), indent=1), "```"]
     open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
+    if len(sys.argv) > 7 and fetch and write:
+        src_hash = open(sys.argv[6]).read().strip()
+        config = sys.argv[7]
+        k = [n for n in fetch if "k_raster_c" in n][0]
+        tpath = os.path.join(prof, f"{tag.split('_')[0]}_traffic.json")
+        j = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        if j.get("csrc_sha256") != src_hash:
+            j = {}
+        j["_provenance"] = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) -- python3 bench.py --steps 3 "
+                            "--warmup 1 --prime 4 --no-cpu-baseline on MI355X; per-launch means of k_raster_c, KiB as reported. bench.py "
+                            "applies the guide's gfx950 correction (FETCH_SIZE x 2) and reports the raw figures beside it.")
+        j["csrc_sha256"] = src_hash
+        j[config] = {"kernel": k, "fetch_kib_raw": round(fetch[k], 1), "write_kib": round(write[k], 1)}
+        json.dump(j, open(tpath, "w"), indent=1)
     print("\n".join(lines[:20]))
 
 
