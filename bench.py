@@ -46,8 +46,8 @@ def build_scene(name, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--prime", type=int, default=32, help="untimed setup frames before warmup (runtime/buffer initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

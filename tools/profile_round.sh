@@ -9,7 +9,7 @@
 TAG=${1:-r02}
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 export TMPDIR=/tmp
-B="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+B="python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 S="python3 bench.py --steps 3 --warmup 1 --prime 4 --no-cpu-baseline --no-profile-events"
 P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY"
 P2="SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"
@@ -26,6 +26,6 @@ python3 bench.py > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err &&
 tail -1 gpurun_out/bench_$TAG.json | cut -c1-300 &&
 for c in cfg2 cfg4 cfg5; do
   rm -rf gpurun_out/prof_${TAG}_$c
-  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG}_$c -o run --output-format csv -- python3 bench.py --config $c --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/bench_${TAG}_$c.json 2> gpurun_out/prof_${TAG}_$c.err || exit 1
+  rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${TAG}_$c -o run --output-format csv -- python3 bench.py --config $c --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${TAG}_$c.json 2> gpurun_out/prof_${TAG}_$c.err || exit 1
   echo "$c done"
 done
