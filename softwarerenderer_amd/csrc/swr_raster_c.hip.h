@@ -307,15 +307,19 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_RASTER_MINWAVES
 #define SWR_RASTER_MINWAVES 4
 #endif
-#define SWR_BATCH_FRAGS (SWR_BATCH * 256)      // a pair covers <= 256 pixels
+#ifndef SWR_BATCH_FRAGS
+#define SWR_BATCH_FRAGS 2048                   // fragments per batch (a pair covers <= 256 pixels, so at least 8 pairs always fit)
+#endif
 #ifndef SWR_WINDOW
 #define SWR_WINDOW 32                          // candidate pairs examined per batch (<= 64)
 #endif
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
-//   3: row steps b12,b20,b01                  4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the
-//   output's wn.z), color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
+//   3: row steps b12,b20,b01, stream position of the pair's first fragment (int bits)
+//   4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the output's wn.z, y by the refined reciprocal of clip.w),
+//   color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
+// LDS per wave is the occupancy limit (4 waves per SIMD = 10,240 B): 10,192 B used.
 template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
     static constexpr int NQ = PHONG ? 16 : 13;
@@ -324,10 +328,12 @@ struct __attribute__((aligned(16))) WaveLdsC {
     float4 stage[NQ][SWR_BATCH];     // batch (non-empty pairs only, compacted): per-pair fragment inputs
     uint32_t mask[SWR_BATCH][8];     // coverage masks
     uint32_t wpre[SWR_BATCH][4];     // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
-    uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (pre[t] - 1) set for every pair t >= 1: pair of fragment g = #bits below g
-    uint32_t pre[SWR_BATCH + 4];     // exclusive prefix of covered counts
-    uint32_t touched[64];            // chunk duplicate election: pixel p claimed <=> bit (p >> 6) of word (p & 63) -- neighbouring
+    uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (first - 1) set for every pair t >= 1 (first = its stream position): pair of fragment g = #bits below g
+    uint32_t touched[32];            // chunk duplicate election: pixel p claimed <=> bit (p >> 5) of word (p & 31) -- neighbouring
                                      // pixels (the usual content of a chunk) fall into different words: no same-address atomics
+    float rowtab[3][3][SWR_BATCH];   // [q][edge][pair]: the pair's edge values at the start of its rows 4, 8, 12 (q = 0, 1, 2), i.e.
+                                     // the reference's row chain (Rasterizer.cs:532-534) run once per pair at staging: a fragment's
+                                     // row replay is then at most 3 add steps from the nearest entry instead of up to 15
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -430,19 +436,10 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     unsigned dbg_batches = 0, dbg_chunks = 0, dbg_chunk_lanes = 0, dbg_chain = 0, dbg_chain_c = 0, dbg_sum_r = 0, dbg_sum_c = 0, dbg_hidden = 0;
 #endif
 
-    // Rolling batch (build with -DSWR_ROLL; OFF by default, see below): a batch's fragment count is rarely a multiple of 64, and a partial last chunk costs a full chunk's
-    // instructions.  While the tile's list has more pairs, the tail of a batch (its last fewer-than-64 fragments and the
-    // few pairs they belong to) is carried into the next batch instead: their staged rows move to the first slots, the new
-    // survivors are staged behind them, and the stream continues with full chunks.  Fragment order is untouched.
-    // (Not with the BlendMode.None early-out, whose carry keys name pairs by batch.)
-#ifdef SWR_ROLL
-    const bool ROLL = !EARLYOUT;
-#else
-    const bool ROLL = false;         // measured on cfg3 (gpurun_out/ab_r02l.txt): chunks -7.7 % (62.5 instead of 57.8 fragments per chunk) but
-#endif                               // batches +19 % (a refill stages 16 - carried pairs): k_raster_c 0.456 -> 0.473 ms.  Kept for re-measurement only.
-    int carry_pairs = 0, carry_frags = 0;              // wave-uniform
+    // (A rolling batch -- the tail of a batch carried into the next one so that every chunk is full -- was built and measured
+    //  twice: chunks -7.7 %, batches +19 %, kernel +4 %.  It lives in the history of this file, commit "Rolling batch ...".)
     uint32_t batch_no = 0;
-    for (uint32_t base = 0; base < n || carry_pairs > 0; ++batch_no) {
+    for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
         //      of the window are staged in LDS ----
         const uint32_t pidx = start + base + (uint32_t)lane;
@@ -469,13 +466,15 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE && zb_w < zmin) cnt = 0;
 #endif
         }
-        // take the first SWR_BATCH survivors; the list is consumed up to and including the last one taken
+        // take the first survivors -- at most SWR_BATCH pairs and SWR_BATCH_FRAGS fragments (the running sum is monotone, so the
+        // taken set is a prefix of the survivors; the first one always fits); the list is consumed up to the first survivor left out
         int consumed;
+        const int cscan = wave_incl_scan(cnt, lane);
         {
             const unsigned long long surv = __ballot(cnt > 0);
             const int rank = __popcll(surv & ((1ull << lane) - 1ull));
-            const unsigned long long last = __ballot(cnt > 0 && rank == SWR_BATCH - 1 - carry_pairs);
-            consumed = last ? __ffsll((long long)last) : min(SWR_WINDOW, (int)(n - base));
+            const unsigned long long left_out = __ballot(cnt > 0 && (rank >= SWR_BATCH || cscan > SWR_BATCH_FRAGS));
+            consumed = left_out ? __ffsll((long long)left_out) - 1 : min(SWR_WINDOW, (int)(n - base));
             if (lane >= consumed) cnt = 0;
         }
         const int cnt_seen = lane < consumed ? cnt_in : 0;
@@ -500,13 +499,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
             }
         }
-        const int cincl = wave_incl_scan(cnt, lane) + carry_frags;           // carried fragments come first in the stream
-        const int total = __builtin_amdgcn_readlane(cincl, 63);
+        const int cincl = cscan;                                             // taken lanes precede every lane that was zeroed: their prefix sums stand
+        const int total = consumed > 0 ? __builtin_amdgcn_readlane(cscan, min(consumed, 64) - 1) : 0;
         if (total == 0) continue;
         const unsigned long long nzb = __ballot(cnt > 0);
-        const int ci = carry_pairs + __popcll(nzb & ((1ull << lane) - 1ull));   // slot of this lane's pair (carried pairs hold the first slots)
-        const int n_staged = carry_pairs + __popcll(nzb);
-        if (carry_pairs == 0 && lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
+        if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
             // one round trip: masks, TriRec and the three outputs of every surviving pair
             const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
@@ -546,8 +544,18 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 L.stage[0][ci] = r0;
                 L.stage[1][ci] = make_float4(f1.z, f1.w, f2.x, __uint_as_float(__float_as_uint(f3.w) | (fastdiv ? SWR_FLAG_FASTDIV : 0u) |
                                                                                  (simple_in ? SWR_FLAG_SIMPLE : 0u)));
+                const uint32_t pre = (uint32_t)(cincl - cnt);                    // stream position of the pair's first fragment
                 L.stage[2][ci] = make_float4(a12, a20, a01, __uint_as_float(fs));
-                L.stage[3][ci] = make_float4(b12, b20, b01, 0.0f);
+                L.stage[3][ci] = make_float4(b12, b20, b01, __uint_as_float(pre));
+                if (ci > 0) atomicOr(&L.head[(pre - 1u) >> 5], 1u << ((pre - 1u) & 31u));
+                // the reference's row chain from the pair's first row, 12 steps: the values at rows 4, 8 and 12 are kept
+                float rw0 = r0.x, rw1 = r0.y, rw2 = r0.z;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { rw0 += b12; rw1 += b20; rw2 += b01; }                  // :532-534
+                    L.rowtab[q][0][ci] = rw0; L.rowtab[q][1][ci] = rw1; L.rowtab[q][2][ci] = rw2;
+                }
             }
             *reinterpret_cast<uint4*>(&L.mask[ci][0]) = m0;
             *reinterpret_cast<uint4*>(&L.mask[ci][4]) = m1;
@@ -555,9 +563,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                            p4 = p3 + (uint32_t)__popc(m0.w), p5 = p4 + (uint32_t)__popc(m1.x), p6 = p5 + (uint32_t)__popc(m1.y),
                            p7 = p6 + (uint32_t)__popc(m1.z);
             *reinterpret_cast<uint4*>(&L.wpre[ci][0]) = make_uint4(p1 << 16, p2 | (p3 << 16), p4 | (p5 << 16), p6 | (p7 << 16));
-            const uint32_t pre = (uint32_t)(cincl - cnt);
-            L.pre[ci] = pre;
-            if (ci > 0) atomicOr(&L.head[(pre - 1u) >> 5], 1u << ((pre - 1u) & 31u));
         }
 #ifdef SWR_DEBUG_COUNTERS
         ++dbg_batches;
@@ -568,10 +573,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         SWR_WAVE_LDS_SYNC();
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
-        int pos = 0;
-        for (; pos < total;) {
-            // fewer than 64 fragments left, more pairs in the list, and the tail spans few pairs: carry it (see ROLL)
-            if (ROLL && total - pos < 64 && base < n && n_staged - t0 <= SWR_BATCH / 2) break;
+        for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
             // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
@@ -579,8 +581,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
             const uint32_t win_lo = __builtin_amdgcn_alignbit(h1, h0, hs), win_hi = __builtin_amdgcn_alignbit(h2, h1, hs);
             const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
-            int k = valid ? g - (int)L.pre[t] : 0;
             const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
+            int k = valid ? g - (int)__float_as_uint(f3.w) : 0;
             // k-th covered pixel of pair t in row-major order: the mask word by a 16-bit-field compare against the
             // word prefix counts, then a 5-level selection inside the word
             int pix;
@@ -616,12 +618,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             // sharing a pixel loses does not matter: the chunk is cut at the LOWEST loser, so no two lanes before the
             // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
-            L.touched[lane] = (lane == (pix_first & 63)) ? (1u << (pix_first >> 6)) : 0u;
+            if (lane < 32) L.touched[lane] = (lane == (pix_first & 31)) ? (1u << (pix_first >> 5)) : 0u;
             SWR_WAVE_LDS_SYNC();      // the seeding store above -> the other lanes' atomics below
-            const uint32_t pbit = 1u << (pix >> 6);
+            const uint32_t pbit = 1u << (pix >> 5);
             bool dup = false;
 #ifndef SWR_ABL_NOELECT
-            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix & 63], pbit) & pbit) != 0u;
+            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix & 31], pbit) & pbit) != 0u;
 #endif
             const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
@@ -671,7 +673,14 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #ifdef SWR_DEBUG_COUNTERS
                     dbg_nrow = nrow; dbg_ncol = ncol;
 #endif
-                    for (int i = 0; i < nrow; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }                // :532-534
+                    // rows: from the nearest staged row start (rowtab: rows 4, 8, 12 of the pair), at most 3 steps
+                    {
+                        const int q = nrow >> 2, qi = max(q, 1) - 1;
+                        const float t0r = L.rowtab[qi][0][t], t1r = L.rowtab[qi][1][t], t2r = L.rowtab[qi][2][t];
+                        if (q > 0) { w0 = t0r; w1 = t1r; w2 = t2r; }
+                        const int rem = nrow & 3;
+                        for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
+                    }
                     for (int i = 0; i < ncol; ++i) { w0 += f2.x; w1 += f2.y; w2 += f2.z; }                // :527-529
                     w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
@@ -751,44 +760,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 }
             }
             pos += cut;
-        }
-        // ---- carry the unconsumed tail into the next batch (ROLL) ----
-        carry_pairs = 0; carry_frags = 0;
-        if (ROLL && pos < total) {
-            const int t_first = t0;                         // the pair fragment `pos` belongs to
-            const int r = n_staged - t_first;               // 1 .. SWR_BATCH / 2 pairs
-            SWR_WAVE_LDS_SYNC();
-            // new stream positions of the carried pairs (the first one may have started before `pos`: negative is fine)
-            int np = 0;
-            if (lane < r) np = (int)L.pre[t_first + lane] - pos;
-            if (t_first > 0) {
-                // move their staged rows down to slots 0 .. r-1: 32 row slots per pair = NQ stage rows, the mask (2), wpre (1);
-                // every lane reads before any lane writes, and slot j < slot t_first + j, so nothing is overwritten early
-                for (int i0 = 0; i0 < r * 32; i0 += 64) {
-                    const int i = i0 + lane, j = i >> 5, q = i & 31, src = t_first + j;
-                    const bool on = i < r * 32 && q < WaveLdsC<PHONG>::NQ + 3;
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (on) {
-                        if (q < WaveLdsC<PHONG>::NQ) v = *reinterpret_cast<const uint4*>(&L.stage[q][src]);
-                        else if (q < WaveLdsC<PHONG>::NQ + 2) v = *reinterpret_cast<const uint4*>(&L.mask[src][4 * (q - WaveLdsC<PHONG>::NQ)]);
-                        else v = *reinterpret_cast<const uint4*>(&L.wpre[src][0]);
-                    }
-                    SWR_WAVE_LDS_SYNC();
-                    if (on) {
-                        if (q < WaveLdsC<PHONG>::NQ) *reinterpret_cast<uint4*>(&L.stage[q][j]) = v;
-                        else if (q < WaveLdsC<PHONG>::NQ + 2) *reinterpret_cast<uint4*>(&L.mask[j][4 * (q - WaveLdsC<PHONG>::NQ)]) = v;
-                        else *reinterpret_cast<uint4*>(&L.wpre[j][0]) = v;
-                    }
-                    SWR_WAVE_LDS_SYNC();
-                }
-            }
-            if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
-            SWR_WAVE_LDS_SYNC();
-            if (lane < r) {
-                L.pre[lane] = (uint32_t)np;
-                if (lane > 0) atomicOr(&L.head[(uint32_t)(np - 1) >> 5], 1u << ((uint32_t)(np - 1) & 31u));      // np >= 1 for every later pair
-            }
-            carry_pairs = r; carry_frags = total - pos;
         }
     }
 
