@@ -78,22 +78,34 @@ __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, c
     if (f.texel_loaded) tc = texture_unpack(f.texel);
     else if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
     float base[4] = { f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w };
+    // v / |v|: three divisions by one denominator = one refined reciprocal + three division cores (div_core, swr_device.h: the
+    // IEEE quotient bit for bit inside its operand range; anything else -- a zero component, a degenerate vector -- takes `/`),
+    // and the square roots through sqrt_core inside its range
+    auto sqrt_exact = [](float x) { return div_operand_safe(x) ? sqrt_core(x) : sqrtf(x); };
+    auto normalize3 = [](const float v[3], float len, float out[3]) {
+        const float r1 = rcp_refined(len);
+        out[0] = div_core(v[0], len, r1); out[1] = div_core(v[1], len, r1); out[2] = div_core(v[2], len, r1);
+        if (!(div_operand_safe(len) && div_operands_safe3(v[0], v[1], v[2]))) { out[0] = v[0] / len; out[1] = v[1] / len; out[2] = v[2] / len; }
+    };
     float Vd[3] = { u.camera_position[0] - f.wpos[0], u.camera_position[1] - f.wpos[1], u.camera_position[2] - f.wpos[2] };
-    float vl = sqrtf(dot3(Vd[0], Vd[1], Vd[2], Vd[0], Vd[1], Vd[2]));
-    float V[3] = { Vd[0] / vl, Vd[1] / vl, Vd[2] / vl };
+    float vl = sqrt_exact(dot3(Vd[0], Vd[1], Vd[2], Vd[0], Vd[1], Vd[2]));
+    float V[3];
+    normalize3(Vd, vl, V);
     float acc[3] = { 0.1f * base[0], 0.1f * base[1], 0.1f * base[2] };
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
         const swr_point_light& L = u.lights[l];
         float Ld[3] = { L.position[0] - f.wpos[0], L.position[1] - f.wpos[1], L.position[2] - f.wpos[2] };
-        float dist = sqrtf(dot3(Ld[0], Ld[1], Ld[2], Ld[0], Ld[1], Ld[2]));
-        float Ln[3] = { Ld[0] / dist, Ld[1] / dist, Ld[2] / dist };
+        float dist = sqrt_exact(dot3(Ld[0], Ld[1], Ld[2], Ld[0], Ld[1], Ld[2]));
+        float Ln[3];
+        normalize3(Ld, dist, Ln);
         float ndotl = mathf_max(0.0f, dot3(f.wn[0], f.wn[1], f.wn[2], Ln[0], Ln[1], Ln[2]));
         float att = math_clamp(1.0f - dist / L.range, 0.0f, 1.0f);
         att = att * att;
         float Hd[3] = { Ln[0] + V[0], Ln[1] + V[1], Ln[2] + V[2] };
-        float hl = sqrtf(dot3(Hd[0], Hd[1], Hd[2], Hd[0], Hd[1], Hd[2]));
-        float H[3] = { Hd[0] / hl, Hd[1] / hl, Hd[2] / hl };
+        float hl = sqrt_exact(dot3(Hd[0], Hd[1], Hd[2], Hd[0], Hd[1], Hd[2]));
+        float H[3];
+        normalize3(Hd, hl, H);
         float sp = mathf_max(0.0f, dot3(f.wn[0], f.wn[1], f.wn[2], H[0], H[1], H[2]));
         sp = sp * sp; sp = sp * sp; sp = sp * sp; sp = sp * sp;
         float k = L.intensity * att;
