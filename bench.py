@@ -86,9 +86,12 @@ def main():
             class ReduceOp: SUM = 0; MAX = 1
             def barrier(self): pass
             def all_reduce(self, t, op=None): pass
-            def gather(self, t, gather_list=None, dst=0, group=None):
+            class _Work:
+                def wait(self): return True
+            def gather(self, t, gather_list=None, dst=0, group=None, async_op=False):
                 if gather_list is not None:
                     gather_list[0].copy_(t[:gather_list[0].shape[0]])
+                return self._Work() if async_op else None
             def destroy_process_group(self): pass
         dist = _FakeDist()
         world = args.fake_world
@@ -159,52 +162,69 @@ def main():
         y0, nrows = multigpu.band_pixel_rows(H, band)
         peer_rows = peer_frame[y0:y0 + nrows]              # contiguous rows of rank 0's frame = this rank's band
     renderer = scenes.SceneRenderer(dev, scene, window=window)
-    state = {"i": 0, "pending": None, "render_ms": 0.0, "ev": [], "replays": dev.replay_count() if world > 1 else 0, "resent": 0}
+    state = {"i": 0, "works": [None] * (len(color_t) if color_t else 1), "ev": [], "since_check": 0,
+             "replays": dev.replay_count() if world > 1 else 0, "resent": 0, "last_k": None}
+    xfer = torch.cuda.Stream() if world > 1 else None      # rank 0: post-collective assembly (stripes / unequal bands), off the render stream
+    stripe_bufs = None
 
     def send_band(k):
-        """flatten (on the GPU) + hand the band of buffer k to rank 0; everything stream-ordered behind the frame's kernels"""
+        """flatten (on the GPU) + hand the band of buffer k to rank 0, stream-ordered behind the frame's kernels and WITHOUT making
+        the render stream wait for the transfer; returns the collective's handle (None for p2p)"""
+        nonlocal stripe_bufs
         if p2p:
-            window.FlattenToAsync(peer_rows.data_ptr())
-            return
+            window.FlattenToAsync(peer_rows.data_ptr())     # the kernel's stores ARE the transfer (peer-mapped pointer over xGMI)
+            return None
         if rgb:
             window.FlattenToAsync(rgb_t[k].data_ptr())     # present payload: Vector4 -> Vector3 on the GPU (MainWindow.cs:234-240)
         payload = rgb_t[k] if rgb else color_t[k]
         if args.stripes > 0:
             # stripes: gather the per-rank stripe buffers, then one indexed row copy per rank scatters them into the frame
-            if rank == 0 and state.get("stripe_bufs") is None:
-                state["stripe_bufs"] = [torch.empty_like(payload) for _ in range(world)]
-            dist.gather(payload, gather_list=state.get("stripe_bufs") if rank == 0 else None, dst=0)
+            if rank == 0 and stripe_bufs is None:
+                stripe_bufs = [[torch.empty_like(payload) for _ in range(world)] for _ in range(len(color_t))]
+            w = dist.gather(payload, gather_list=stripe_bufs[k] if rank == 0 else None, dst=0, async_op=True)
             if rank == 0:
-                multigpu.assemble_stripes(state["stripe_bufs"], H, world, args.stripes, frame=frame_t)
-            return
-        multigpu.gather_bands(payload, H, W, rank, world, dst=0, frame=frame_t, dist=dist)
+                with torch.cuda.stream(xfer):
+                    w.wait()
+                    multigpu.assemble_stripes(stripe_bufs[k], H, world, args.stripes, frame=frame_t)
+            return w
+        return multigpu.gather_bands(payload, H, W, rank, world, dst=0, frame=frame_t, dist=dist, async_op=True, post_stream=xfer)[1]
 
-    def validate_previous():
-        """The stream has drained: let the backend look at its optimistic batches.  If one had not fitted (never in steady
-        state) swr_sync has replayed it into the buffer it was flushed against; the payload sent meanwhile was stale: resend."""
-        dev.sync()
-        r = dev.replay_count()
-        if r != state["replays"] and state["pending"] is not None:
-            state["replays"] = r
-            k = state["pending"]
-            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
-            send_band(k)
-            torch.cuda.current_stream().synchronize()
-            state["resent"] += 1
+    def before_reuse(k):
+        """buffer k was last used two frames ago: its transfer must be over before the next frame renders into it.  A stream-level
+        wait (RCCL work handle / the assembly stream): the host does not block, the GPU runs back to back."""
+        w = state["works"][k]
+        if w is not None:
+            w.wait()
+            state["works"][k] = None
+        if xfer is not None and rank == 0:
+            torch.cuda.current_stream().wait_stream(xfer)
 
-    def wait_gather():
-        if state["pending"] is not None:
-            torch.cuda.current_stream().synchronize()      # the previous frame's bands have arrived / been sent
-            if p2p and not args.fake_world:
-                dist.barrier()                              # every rank's stores into rank 0's frame have completed
-            validate_previous()
-            state["pending"] = None
-
-    def barrier():
-        wait_gather()
-        if world > 1:
+    def checkpoint():
+        """Every few frames and at every barrier: drain, confirm across ranks that all stores / collectives are complete, and let the
+        backend look at its optimistic batches (swr_sync validates and replays).  A replay (never in steady state) means the payload
+        of the frames sent since is stale: the last one is sent again."""
+        for k in range(len(state["works"])):
+            before_reuse(k)
+        torch.cuda.current_stream().synchronize()
+        if xfer is not None:
+            xfer.synchronize()
+        if world > 1 and not args.fake_world:
             dist.barrier()
         dev.sync()
+        r = dev.replay_count()
+        if world > 1 and r != state["replays"] and state["last_k"] is not None:
+            state["replays"] = r
+            k = state["last_k"]
+            window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
+            w = send_band(k)
+            if w is not None:
+                w.wait()
+            torch.cuda.current_stream().synchronize()
+            state["resent"] += 1
+        state["since_check"] = 0
+
+    def barrier():
+        checkpoint()
         torch.cuda.synchronize()
 
     def step():
@@ -214,6 +234,7 @@ def main():
             return
         k = state["i"] % len(color_t)
         state["i"] += 1
+        before_reuse(k)
         if len(color_t) > 1:
             window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())     # no host wait (a batch remembers its target)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -222,13 +243,13 @@ def main():
         dev.flush()
         e1.record()                                         # render leg of this rank, on the stream the kernels run on
         state["ev"].append((e0, e1))
-        wait_gather()         # one gather in flight at a time (it fills the same frame on rank 0)
-        send_band(k)
-        if overlap:
-            state["pending"] = k          # completes while the next frame renders into the other buffer
-        else:
-            state["pending"] = k
-            wait_gather()
+        state["works"][k] = send_band(k)                    # the transfer of frame i overlaps the rendering of frame i+1
+        state["last_k"] = k
+        if not overlap:
+            before_reuse(k)
+        state["since_check"] += 1
+        if state["since_check"] >= 32:
+            checkpoint()
 
     # Setup (untimed, not part of warmup): the first frame sizes the pair buffers synchronously, and the HIP runtime
     # that torch bundles spends a one-off ~45 ms around its 16th submission (measured: tools/host_timing2.py) growing

@@ -83,17 +83,22 @@ def max_band_rows(height: int, world_size: int) -> int:
     return max(band_pixel_rows(height, b)[1] for b in band_partition(height, world_size))
 
 
-def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None, dist=None):
+def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None, dist=None,
+                 async_op: bool = False, post_stream=None):
     """Gather the per-rank colour bands (torch tensors of shape (max_band_rows, width, C), rows beyond a
     band's own count are padding) to `dst`; returns the assembled (height, width, C) frame there, else None.
     `frame` (optional, dst only) is a preallocated output.  When every band has the same number of pixel rows
     the receive buffers ARE row blocks of the frame (no assembly copy).  Works on any backend
-    (nccl == RCCL on ROCm; gloo on CPU for the tests)."""
+    (nccl == RCCL on ROCm; gloo on CPU for the tests).
+    async_op=True returns (frame, work) without making the calling stream wait for the collective: the caller keeps
+    rendering and calls work.wait() only before it reuses `local_band` (RCCL: a stream-level wait, the host never blocks).
+    Bands of unequal size need a copy after the collective; in async mode it runs on `post_stream` behind the collective."""
     import torch
     if dist is None:
         import torch.distributed as dist
     if world_size == 1:
-        return local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
+        out = local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
+        return (out, None) if async_op else out
     bands = band_partition(height, world_size)
     rows = [band_pixel_rows(height, b) for b in bands]
     bufs = None
@@ -105,14 +110,28 @@ def gather_bands(local_band, height: int, width: int, rank: int, world_size: int
             bufs = [frame[y0:y0 + n] for (y0, n) in rows]          # contiguous row blocks: receive in place
         else:
             bufs = [torch.empty_like(local_band) for _ in range(world_size)]
-    dist.gather(local_band, gather_list=bufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    if not uniform:
+    work = dist.gather(local_band, gather_list=bufs, dst=dst, group=group, async_op=True) if async_op else \
+        dist.gather(local_band, gather_list=bufs, dst=dst, group=group)
+
+    def assemble():
         for r, (y0, n) in enumerate(rows):
             if n:
                 frame[y0:y0 + n] = bufs[r][:n]
-    return frame
+
+    if rank == dst and not uniform:
+        if async_op and local_band.is_cuda:
+            stream = post_stream if post_stream is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):
+                if work is not None:
+                    work.wait()
+                assemble()
+        else:
+            if async_op and work is not None:
+                work.wait()
+            assemble()
+    if async_op:
+        return (frame if rank == dst else None), work
+    return frame if rank == dst else None
 
 
 def assemble_numpy(bands: List[np.ndarray], height: int, world_size: int) -> np.ndarray:
