@@ -219,11 +219,13 @@ def test_retained_mesh_reuse_and_stats(device):
     assert st["flushes"] == 3 and st["tile_pairs"] > 0
 
 
-def test_optimistic_flush_overflow_is_replayed_exactly(device):
+def test_optimistic_flush_overflow_is_replayed_exactly():
     """Flushes run without reading the pair total back; a batch that does not fit the pair buffers poisons itself and
     every later batch on the device, and the host replays them at the next synchronisation point.  Force that path:
     size the buffers with a tiny scene, then submit two much larger, order-dependent frames back to back."""
     from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    device = Device(0)                       # a fresh context (the session's shared one may already own large pair buffers)
     small = scenes.cfg2(256, 256, 40, seed=50, min_area=10.0, max_area=60.0)
     big1 = scenes.cfg2(256, 256, 3000, seed=51, min_area=200.0, max_area=9000.0)
     big2 = scenes.state_scene(256, 256, 2500, seed=52, blend=BlendMode.Additive)
@@ -241,10 +243,13 @@ def test_optimistic_flush_overflow_is_replayed_exactly(device):
     r2 = scenes.SceneRenderer(device, big2, window=r0.window)
     r1.submit_frame(); device.flush()                           # optimistic: overflows -> poison
     r2.submit_frame(); device.flush()                           # skipped on the device while poisoned
+    replays = device.replay_count()
     c, d = r0.window._read()                                    # sync point: validate + replay, then read
+    assert device.replay_count() == replays + 1                 # the path under test really ran
     st = device.stats()
     for r in (r0, r1, r2):
         r.close()
+    device.close()
     assert_frame_parity(c, d, rc, rd, 1, "replay")
     for k in ("triangles_in", "triangles_setup", "fragments_tested", "fragments_shaded", "fragments_written"):
         assert st[k] == rst[k], (k, st[k], rst[k])
@@ -477,3 +482,41 @@ def test_interleaved_stripes_union_is_the_single_gpu_frame(device, world, k):
     d = multigpu.assemble_stripes(deps, scene.height, world, k)
     assert_frame_parity(c, d, rc, rd, 1, f"stripes world={world} k={k}")
     assert frag == ost["fragments_written"]
+
+
+def test_async_flatten_and_deferred_validation():
+    """The multi-GPU frame loop's contract (bench.py, N > 1): flatten without validating, consume in stream order, validate later.
+    swr_replay_count tells the caller that a batch was replayed, i.e. that a payload flattened before the validating swr_sync is
+    stale; flattening again after it gives the frame of the oracle."""
+    import torch
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    device = Device(0)                                                # a fresh context: its pair buffers start empty
+    small = scenes.cfg2(256, 256, 40, seed=60, min_area=10.0, max_area=60.0)
+    big = scenes.cfg2(256, 256, 3000, seed=61, min_area=200.0, max_area=9000.0)
+    o = OracleRenderer(256, 256)
+    rc, _ = o.render_scene(big)
+    r0 = scenes.SceneRenderer(device, small)
+    r0.render()                                                       # synchronous sizing of the pair buffers (small)
+    rgb = torch.zeros((256, 256, 3), dtype=torch.float32, device="cuda")
+    before = device.replay_count()
+    r1 = scenes.SceneRenderer(device, big, window=r0.window)
+    r1.submit_frame()                                                 # optimistic flush that does not fit -> poisoned on the device
+    r0.window.FlattenToAsync(rgb.data_ptr())                          # no validation, no wait: flattens the UNCHANGED framebuffer
+    device.sync()                                                     # validates: replays the batch
+    assert device.replay_count() == before + 1                        # ... and says so
+    stale = rgb.cpu().numpy().copy()
+    r0.window.FlattenToAsync(rgb.data_ptr())                          # the caller's reaction: flatten (and send) again
+    device.sync()
+    assert device.replay_count() == before + 1
+    fresh = rgb.cpu().numpy()
+    assert ulp_distance(fresh, rc[..., :3]).max() <= 1
+    assert not np.array_equal(stale, fresh)                           # the first payload really was stale
+    # steady state: the next frame fits, nothing is replayed, one flatten suffices
+    r1.submit_frame()
+    r0.window.FlattenToAsync(rgb.data_ptr())
+    device.sync()
+    assert device.replay_count() == before + 1
+    assert ulp_distance(rgb.cpu().numpy(), rc[..., :3]).max() <= 1
+    r0.close(); r1.close()
+    device.close()
