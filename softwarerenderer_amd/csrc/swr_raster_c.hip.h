@@ -120,8 +120,16 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
             const int w = min((int)(bbx >> 16), min(x0 + SWR_TILE - 1, a.fp.width - 1)) - max((int)(bbx & 0xffffu), x0) + 1;
             const int h = min((int)(bby >> 16), min(y0 + SWR_TILE - 1, a.fp.height - 1)) - max((int)(bby & 0xffffu), y0) + 1;
             area = (w > 0 && h > 0) ? w * h : 0;
+#ifndef SWR_COVER_SORT_AREA
+            // a wave walks max-height rows x max-width columns of its lanes, so group by SHAPE, not just area: bucket = (rows, columns)
+            // quantised to 4 -- 1 + 4 * 4 buckets, tallest / widest first (0 = nothing to walk)
+            if (area > 0) area = 1 + ((h + 3) / 4 - 1) * 4 + ((w + 3) / 4 - 1);
+        }
+        bucket = (uint32_t)area;                                 // 0..16
+#else
         }
         bucket = (uint32_t)(area + 7) >> 3;                      // 0..32
+#endif
         rank = atomicAdd(&s_hist[bucket], 1u);
     }
     __syncthreads();
