@@ -833,15 +833,13 @@ int oswr_render_mesh(oswr_context* c,
     j->ds = ds; j->vertices = vertices; j->indices = indices; j->n_tris = n_tris;
     j->model = model; j->view = view; j->proj = projection;
     atomic_store(&j->next, 0);
-    j->n_chunks = (n_tris + OSWR_CHUNK - 1) / OSWR_CHUNK;
-    j->lanes = pool->n < j->n_chunks ? pool->n : (j->n_chunks > 0 ? j->n_chunks : 1);
-    j->per_lane = (j->n_chunks + j->lanes - 1) / j->lanes;
-    /* the grab counter must cover the (lanes x per_lane) grid, which can exceed n_chunks by up to lanes - 1 slots */
-    j->n_chunks = j->n_chunks;      /* bound for the chunk id; the loop below walks lanes * per_lane grabs */
     {
-        int grid = j->lanes * j->per_lane, real = j->n_chunks;
-        j->n_chunks = grid;                            /* grabs g in [0, grid); run_job skips chunk ids >= real via n_tris */
-        (void)real;
+        /* chunk ids are laid out on a (lanes x per_lane) grid and grabbed column by column, so that simultaneous grabs are far
+         * apart in the mesh; the grid can exceed the real chunk count by up to lanes - 1 ids, which give empty ranges */
+        int real = (n_tris + OSWR_CHUNK - 1) / OSWR_CHUNK;
+        j->lanes = pool->n < real ? pool->n : (real > 0 ? real : 1);
+        j->per_lane = (real + j->lanes - 1) / j->lanes;
+        j->n_chunks = j->lanes * j->per_lane;          /* grabs g in [0, n_chunks) */
     }
     memset(pool->stats, 0, sizeof(oswr_stats) * (size_t)pool->n);
     pthread_mutex_lock(&pool->mu);

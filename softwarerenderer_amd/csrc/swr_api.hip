@@ -763,6 +763,7 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     d.p.verts = mesh->d_verts; d.p.idx = mesh->d_idx;
     d.p.tex = tex ? tex->d_rgba : nullptr;
     d.p.tex_w = tex ? tex->w : 0; d.p.tex_h = tex ? (tex->bilinear ? -tex->h : tex->h) : 0;
+    d.p.tex_wf = tex ? (float)tex->w : 0.0f; d.p.tex_hf = tex ? (float)tex->h : 0.0f;
     d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
     d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
     d.mesh = mesh;
@@ -1103,6 +1104,7 @@ int swr_set_depth(swr_context* c, int x, int y, float d) {
 int swr_texture_create(swr_context* c, const uint8_t* rgba8, int w, int h, swr_texture** out) {
     SWR_ENTER(c);
     if (!rgba8 || w <= 0 || h <= 0 || !out) return fail(c, SWR_ERR_INVALID_ARG, "bad texture arguments");
+    if ((uint64_t)w * (uint64_t)h >= (1ull << 30)) return fail(c, SWR_ERR_UNSUPPORTED, "textures of 2^30 texels or more are not supported (32-bit texel index)");
     swr_texture* t = new swr_texture();
     t->w = w; t->h = h;
     hipError_t e = hipMalloc((void**)&t->d_rgba, (size_t)w * h * 4);

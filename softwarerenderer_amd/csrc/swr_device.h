@@ -71,7 +71,9 @@ struct DrawParams {
     uint32_t vert_base;     // first VOut of this draw
     uint32_t tri_base;      // first global triangle number of this draw
     float fog_r1;           // rcp_refined(u.fog_end - u.fog_start), or 0 when that range is outside div_operand_safe():
-    float pad_;             // written on the device by k_vertex (the fragment program's fog division, Renderer.cs:855)
+                            // written on the device by k_vertex (the fragment program's fog division, Renderer.cs:855)
+    float tex_wf, tex_hf;   // (float)tex_w, (float)|tex_h|: Texture.Sample's `u * Width` / `v * Height` operands (Texture.cs:50-51)
+    float pad_;
 };
 
 struct Counters {           // device-side swr_stats accumulators
@@ -321,19 +323,23 @@ __device__ __forceinline__ float4 texture_unpack(uint32_t p) {              // T
     o.w = (float)(p >> 24) * inv255;
     return o;
 }
-__device__ __forceinline__ size_t texture_nearest_index(int w, int h, float tu, float tv) {      // Texture.cs:43-54
+// wf, hf = (float)Width, (float)Height as C# converts them in `u * Width` (exact for sizes below 2^24; passed in so that the raster
+// kernel gets them from the draw's constants instead of converting per fragment).  32-bit texel index: swr_texture_create refuses
+// textures of 2^30 texels or more, so index * 4 fits the unsigned 32-bit offset of a global load with a scalar base.
+__device__ __forceinline__ uint32_t texture_nearest_index(int w, int h, float wf, float hf, float tu, float tv) {      // Texture.cs:43-54
     float u = tu - (float)f2i(tu);
     float v = tv - (float)f2i(tv);
     u += (u < 0) ? 1.0f : 0.0f;
     v += (v < 0) ? 1.0f : 0.0f;
-    int xi = f2i(u * (float)w);
-    int yi = f2i(v * (float)h);
-    // C# '%' truncates toward zero; the common case 0 <= xi <= w needs no integer division
-    int x = (xi >= 0 && xi < w) ? xi : (xi == w ? 0 : xi % w);
-    int y = (yi >= 0 && yi < h) ? yi : (yi == h ? 0 : yi % h);
-    if (x < 0) x += w;
-    if (y < 0) y += h;
-    return (size_t)y * (size_t)w + (size_t)x;
+    int x = f2i(u * wf);
+    int y = f2i(v * hf);
+    // C# '%' truncates toward zero, then `if (x < 0) x += Width`; the common case 0 <= x < w needs neither
+    if ((uint32_t)x >= (uint32_t)w) { x = (x == w) ? 0 : x % w; if (x < 0) x += w; }
+    if ((uint32_t)y >= (uint32_t)h) { y = (y == h) ? 0 : y % h; if (y < 0) y += h; }
+    return (uint32_t)y * (uint32_t)w + (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t texture_nearest_index(int w, int h, float tu, float tv) {
+    return texture_nearest_index(w, h, (float)w, (float)h, tu, tv);
 }
 __device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
     return texture_unpack(reinterpret_cast<const uint32_t*>(tex)[texture_nearest_index(w, h, tu, tv)]);

@@ -167,7 +167,9 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     f.texel = 0u; f.texel_loaded = false;
 #ifndef SWR_ABL_NOTEX
     if (dp->tex && dp->tex_h > 0) {
-        f.texel = reinterpret_cast<const uint32_t*>(dp->tex)[texture_nearest_index(dp->tex_w, dp->tex_h, f.u, f.v)];
+        // global (not generic) address space + 32-bit index: one global_load with the draw's texture pointer as scalar base
+        typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+        f.texel = ((global_u32_ptr)(uintptr_t)dp->tex)[texture_nearest_index(dp->tex_w, dp->tex_h, dp->tex_wf, dp->tex_hf, f.u, f.v)];
         f.texel_loaded = true;
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address

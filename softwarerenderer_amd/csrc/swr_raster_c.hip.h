@@ -36,6 +36,10 @@ namespace swr {
 // window prefetch at the loop top): wave_min's DPP ladder is a plain `asm` for that reason.
 #define SWR_WAVE_LDS_SYNC() ((void)0)
 
+// wave64 ballot straight from a bool: HIP's __ballot(int) first materialises the predicate as 0 / 1 in a VGPR and compares it
+// with zero again (two VALU instructions per use in a VALU-bound kernel); the builtin takes the condition mask as it is
+#define SWR_BALLOT(cond) __builtin_amdgcn_ballot_w64((bool)(cond))
+
 // Inclusive prefix sum over the wave, on the DPP path (no LDS round trips): Hillis-Steele inside each row of 16 lanes
 // with row_shr, then the row totals with row_bcast:15 (rows 1, 3) and row_bcast:31 (rows 2, 3).  All 64 lanes must be active.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         const uint32_t next_tile = (uint32_t)__shfl_down((int)tile, 1);
         const bool run_end = lane == 63 || next_tile != tile;
         const uint32_t prev_tile = (uint32_t)__shfl_up((int)tile, 1);
-        const unsigned long long starts = __ballot(lane == 0 || prev_tile != tile);
+        const unsigned long long starts = SWR_BALLOT(lane == 0 || prev_tile != tile);
         const unsigned long long upto = starts & ((2ull << lane) - 1ull);                  // run starts at or below this lane
         const int first = 63 - __clzll((long long)upto);
         const int before = __shfl(incl - cnt, first);                                      // prefix before the run
@@ -479,9 +483,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         int consumed;
         const int cscan = wave_incl_scan(cnt, lane);
         {
-            const unsigned long long surv = __ballot(cnt > 0);
+            const unsigned long long surv = SWR_BALLOT(cnt > 0);
             const int rank = __popcll(surv & ((1ull << lane) - 1ull));
-            const unsigned long long left_out = __ballot(cnt > 0 && (rank >= SWR_BATCH || cscan > SWR_BATCH_FRAGS));
+            const unsigned long long left_out = SWR_BALLOT(cnt > 0 && (rank >= SWR_BATCH || cscan > SWR_BATCH_FRAGS));
             consumed = left_out ? __ffsll((long long)left_out) - 1 : min(SWR_WINDOW, (int)(n - base));
             if (lane >= consumed) cnt = 0;
         }
@@ -510,7 +514,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         const int cincl = cscan;                                             // taken lanes precede every lane that was zeroed: their prefix sums stand
         const int total = consumed > 0 ? __builtin_amdgcn_readlane(cscan, min(consumed, 64) - 1) : 0;
         if (total == 0) continue;
-        const unsigned long long nzb = __ballot(cnt > 0);
+        const unsigned long long nzb = SWR_BALLOT(cnt > 0);
         const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
         if (lane < SWR_BATCH_FRAGS / 128 + 1) *reinterpret_cast<uint4*>(&L.head[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
         if (cnt > 0) {
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 const int wi = nle - 1;
                 const uint32_t wsel = L.mask[t][wi];
                 const int kw = k - (int)reinterpret_cast<const uint16_t*>(&L.wpre[t][0])[wi];
-                const bool okk = valid && kw < __popc(wsel);         // always true for a valid fragment
+                const bool okk = valid;                              // (kw < popc(wsel) holds for every valid fragment)
                 // the word holds two rows; when each is one run (SWR_FLAG_SIMPLE, nearly always) the k-th covered pixel
                 // is first-pixel-of-the-run + k
                 const bool simple = (__float_as_uint(f1.w) & SWR_FLAG_SIMPLE) != 0u;
@@ -611,7 +615,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 const bool up = kw >= c0;
                 const uint32_t half = up ? (wsel >> 16) : lo;
                 int posw = (up ? 16 + (kw - c0) : kw) + (__ffs((int)half) - 1);
-                if (__ballot(okk && !simple) != 0ull) {
+                // (a ballot of ONE compare is the compare's own mask; invalid lanes index some staged pair, at worst a spurious general pass)
+                if (SWR_BALLOT((__float_as_uint(f1.w) & SWR_FLAG_SIMPLE) == 0u) != 0ull) {
                     if (!simple) posw = kth_set_bit32(wsel, okk ? kw : 0);
                 }
                 pix = (wi * 32 + posw) & 255;
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
-            const unsigned long long stop = __ballot(!valid || dup || draw != draw0);
+            const unsigned long long stop = SWR_BALLOT(!valid || dup || draw != draw0);
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
             {
                 const unsigned long long win = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)win_hi) << 32) |
@@ -739,8 +744,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 if (none) {
                     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
                     const bool head = act && (lane == 0 || key != prev);
-                    const unsigned long long H = __ballot(head);
-                    const unsigned long long F = __ballot(act && e_pass && !e_alpha);
+                    const unsigned long long H = SWR_BALLOT(head);
+                    const unsigned long long F = SWR_BALLOT(act && e_pass && !e_alpha);
                     const unsigned long long below = (1ull << lane) - 1ull;
                     const unsigned long long hm = H & (below | (1ull << lane));
                     const int headlane = hm ? 63 - __clzll((long long)hm) : 0;
