@@ -39,8 +39,11 @@ def assert_frame_parity(color, depth, ref_color, ref_depth, color_ulp=1, what=""
 
 
 def render_oracle(scene, debug_mode=0, threads=1):
+    """SWR_ORACLE_VARIANT (fma / dotpw / fma_dotpw / dpps) selects the oracle build that matches a System.Numerics sensitivity
+    build of the backend (SWR_LIB=libswr_hip_<variant>.so): used by the sweeps in tools/, never by the suite's own defaults."""
+    import os
     from oracle.binding import OracleRenderer
-    o = OracleRenderer(scene.width, scene.height, threads=threads)
+    o = OracleRenderer(scene.width, scene.height, threads=threads, variant=os.environ.get("SWR_ORACLE_VARIANT") or None)
     c, d = o.render_scene(scene, debug_mode)
     st = o.stats()
     o.close()
