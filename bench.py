@@ -252,7 +252,7 @@ def main():
             checkpoint()
 
     # Setup (untimed, not part of warmup): the first frame sizes the pair buffers synchronously, and the HIP runtime
-    # that torch bundles spends a one-off ~45 ms around its 16th submission (measured: tools/host_timing2.py) growing
+    # that torch bundles spends a one-off ~45 ms around its 16th submission growing
     # internal pools.  Prime past both so that the W warmup + K timed steps see the steady state.
     t_prime = time.perf_counter()
     n_prime = 0
