@@ -926,6 +926,9 @@ int swr_bind_framebuffer(swr_context* c, void* color, void* depth) {
     // buffers pays no host round trip here)
     int rc = flush_locked(c);
     if (rc) return rc;
+    // back to internal storage: apply_geometry may have to (re)allocate it, which must not happen under batches that could
+    // still be replayed against the old allocation -- drain and validate first (binding caller memory never allocates)
+    if (!color && (rc = sync_locked(c))) return rc;
     c->ext_color = color; c->ext_depth = depth;
     return apply_geometry(c);
 }
