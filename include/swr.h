@@ -226,7 +226,8 @@ int  swr_device_name(swr_context* ctx, char* buf, int buflen);
 /* Self-test of the kernels' exact-division shortcut (csrc/swr_device.h: div_core / rcp_refined / sqrt_core): about
  * `samples` random, near-midpoint, boundary and renderer-shaped operand pairs are divided both ways on the GPU and compared bit
  * for bit with the compiler's correctly rounded `/` and sqrtf (the IEEE results the reference's C# computes, Rasterizer.cs:576-582,
- * 684-686, Renderer.cs:855).  out = {divisions tested, mismatches, sqrts tested, mismatches, first bad n, d, got, want}. */
+ * 684-686, Renderer.cs:855); the reciprocal core (recip_core, n = 1) is checked on EVERY float of its range, both signs, on top
+ * of `samples`.  out = {divisions tested, mismatches, sqrts tested, mismatches, first bad n, d, got, want}. */
 int  swr_selftest_division(swr_context* ctx, uint64_t samples, uint64_t seed, uint64_t out[8]);
 /* kernel-internal work counters; all zero unless the library was built with -DSWR_DEBUG_COUNTERS (tools/) */
 int  swr_debug_counters(swr_context* ctx, uint64_t out[8]);

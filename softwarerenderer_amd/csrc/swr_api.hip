@@ -1347,6 +1347,9 @@ int swr_selftest_division(swr_context* c, uint64_t samples, uint64_t seed, uint6
     if (blocks) hipLaunchKernelGGL(k_selftest_division, dim3(blocks), dim3(256), 0, c->stream, (unsigned long long)seed, iters,
                                    c->d_scratch.as<unsigned long long>());
     SWR_HIP(c, hipGetLastError());
+    // reciprocals (recip_core): exhaustive over its whole range, whatever `samples` says
+    hipLaunchKernelGGL(k_selftest_recip, dim3(16384), dim3(256), 0, c->stream, c->d_scratch.as<unsigned long long>());
+    SWR_HIP(c, hipGetLastError());
     SWR_HIP(c, hipMemcpyAsync(out, c->d_scratch.p, 64, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
 }

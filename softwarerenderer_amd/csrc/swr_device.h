@@ -73,8 +73,9 @@ struct DrawParams {
     float fog_r1;           // rcp_refined(u.fog_end - u.fog_start), or 0 when that range is outside div_operand_safe():
                             // written on the device by k_vertex (the fragment program's fog division, Renderer.cs:855)
     float tex_wf, tex_hf;   // (float)tex_w, (float)|tex_h|: Texture.Sample's `u * Width` / `v * Height` operands (Texture.cs:50-51)
-    float pad_;
+    float fog_den;          // u.fog_end - u.fog_start, written next to fog_r1 by k_vertex: one float subtraction per draw, not per fragment
 };
+static_assert(offsetof(DrawParams, fog_den) == offsetof(DrawParams, fog_r1) + 12, "k_vertex writes fog_den three floats after fog_r1");
 
 struct Counters {           // device-side swr_stats accumulators
     unsigned long long triangles_in, triangles_setup, triangles_clipped;
@@ -183,11 +184,31 @@ __device__ __forceinline__ float div_core(float n, float d, float r1) {
 #define SWR_DIV_LO_BITS 0x2B800000u      // 2^-40
 #define SWR_DIV_HI_BITS 0x53800000u      // 2^40
 __device__ __forceinline__ bool div_operand_safe(float v) {
-    return ((__float_as_uint(v) & 0x7fffffffu) - SWR_DIV_LO_BITS) <= (SWR_DIV_HI_BITS - SWR_DIV_LO_BITS);
+    return __builtin_fabsf(v) >= 0x1p-40f && __builtin_fabsf(v) <= 0x1p40f;       // two compares with the |.| source modifier; NaN fails both
 }
 __device__ __forceinline__ bool div_operands_safe3(float a, float b, float c) {
     const uint32_t ua = __float_as_uint(a) & 0x7fffffffu, ub = __float_as_uint(b) & 0x7fffffffu, uc = __float_as_uint(c) & 0x7fffffffu;
     return min(min(ua, ub), uc) >= SWR_DIV_LO_BITS && max(max(ua, ub), uc) <= SWR_DIV_HI_BITS;
+}
+// The same guard for three values that are results of float arithmetic (canonical, so min/add need no quieting):
+// 5 instructions instead of 7.  The sum of the magnitudes is >= each of them and carries NaN / Inf (a NaN is dropped by
+// v_min3 but not by the sum), so `sum <= 2^40` bounds all three from above -- slightly conservative, which a guard may be.
+__device__ __forceinline__ bool div_operands_safe3_arith(float a, float b, float c) {
+    const float fa = __builtin_fabsf(a), fb = __builtin_fabsf(b), fc = __builtin_fabsf(c);
+    const float sum = (fa + fb) + fc;
+    const float lo = __builtin_fminf(__builtin_fminf(fa, fb), fc);
+    return lo >= 0x1p-40f && sum <= 0x1p40f;
+}
+// 1 / d: the division core with n = 1 (q0 = 1 * r1 is r1 itself): 7 instructions instead of 11.  With n = 1 the range is
+// wider on the large side: |d| in [2^-40, 2^83] (v_div_scale rescues only |d| >= 2^126, |d| <= 2^-96 and denormals).
+// swr_selftest_division checks EVERY float of that range, both signs, against the compiler's 1.0f / d.
+#define SWR_RCP_HI_BITS 0x69000000u      // 2^83
+__device__ __forceinline__ float recip_core(float d) {
+    const float r1 = rcp_refined(d);
+    const float e2 = __builtin_fmaf(-d, r1, 1.0f);
+    const float q1 = __builtin_fmaf(e2, r1, r1);
+    const float e3 = __builtin_fmaf(-d, q1, 1.0f);
+    return __builtin_fmaf(e3, r1, q1);
 }
 // hipcc's correctly rounded sqrtf is: scale x by 2^32 if x < 2^-96; s = v_sqrt_f32(x); step s down one ulp if
 // fma(-(s-1ulp), s, x) <= 0, up one ulp if fma(-(s+1ulp), s, x) > 0; unscale; return x itself for +-0 / +inf.

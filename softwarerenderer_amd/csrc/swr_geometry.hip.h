@@ -22,7 +22,7 @@ struct BlockMap { uint32_t draw; uint32_t first; };
 __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ draws,
                                                 const BlockMap* __restrict__ blocks,
                                                 VOut* __restrict__ vout, const uint32_t* __restrict__ visible,
-                                                float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: written, never read here */) {
+                                                float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */) {
     const BlockMap bm = blocks[blockIdx.x];
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
     if (local == 0u) {      // once per draw: the refined reciprocal of the fog range (see div_core in swr_device.h)
         const float den = dp->u.fog_end - dp->u.fog_start;
         fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float))] = div_operand_safe(den) ? rcp_refined(den) : 0.0f;
+        fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float)) + 3] = den;      // DrawParams::fog_den
     }
 
     const float* __restrict__ vin = reinterpret_cast<const float*>(dp->verts + local);

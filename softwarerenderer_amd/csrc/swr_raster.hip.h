@@ -49,7 +49,7 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     // (FogEnd - depth) / (FogEnd - FogStart), Renderer.cs:855: the denominator is per draw, its refined reciprocal was
     // computed once by k_vertex (dp->fog_r1, 0 = out of the safe range) -- see div_core in swr_device.h
-    const float fog_num = u.fog_end - f.clip_z, fog_den = u.fog_end - u.fog_start;
+    const float fog_num = u.fog_end - f.clip_z, fog_den = dp->fog_den;       // (= u.fog_end - u.fog_start, k_vertex)
     float fog_q = div_core(fog_num, fog_den, dp->fog_r1);
     if (!(dp->fog_r1 != 0.0f && div_operand_safe(fog_num))) fog_q = fog_num / fog_den;
     float fog = math_clamp(fog_q, 0.0f, 1.0f);
@@ -147,13 +147,22 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     float ra = div_core(w0f, a_clip.w, V.a_r1);
     float rb = div_core(w1f, b_clip.w, V.b_r1);
     float rc = div_core(w2f, c_clip.w, V.c_r1);
-    if (!(V.fastdiv && div_operands_safe3(w0f, w1f, w2f))) {
-        ra = w0f / a_clip.w;
-        rb = w1f / b_clip.w;
-        rc = w2f / c_clip.w;
-    }
+    const bool fast = V.fastdiv && div_operands_safe3_arith(w0f, w1f, w2f);
     float inv_sum = (ra + rb) + rc;         // :579
-    float w = 1.0f / inv_sum;               // :582
+    // :582.  On the fast path |ra|, |rb|, |rc| <= 2^40 / 2^-40, so |inv_sum| < 2^82: inside recip_core's range unless it
+    // is tiny (cancellation), zero or NaN
+    float w = recip_core(inv_sum);
+    if (!(fast && __builtin_fabsf(inv_sum) >= 0x1p-40f)) {
+        // one cold block for everything outside the cores' ranges (a single division on its own would be if-converted
+        // into a select, i.e. computed by every fragment)
+        if (!fast) {
+            ra = w0f / a_clip.w;
+            rb = w1f / b_clip.w;
+            rc = w2f / c_clip.w;
+        }
+        inv_sum = (ra + rb) + rc;
+        w = 1.0f / inv_sum;
+    }
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
     Frag f;
     if (simple) {
@@ -190,8 +199,11 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         float n2 = (V.a_wnz * wa + V.b_wnz * wb) + V.c_wnz * wc;
         float len_sq = dot3(n0, n1, n2, n0, n1, n2);
         if (len_sq > 1e-6f) {
-            // 1 / MathF.Sqrt(lenSq): both correctly rounded; inside sqrt_core's range the square root needs no scaling
-            float s = 1.0f / (len_sq <= 1.0e12f ? sqrt_core(len_sq) : sqrtf(len_sq));
+            // 1 / MathF.Sqrt(lenSq): both correctly rounded; for lenSq in (1e-6, 1e12] the square root needs no scaling and
+            // lies in [1e-3, 1e6], where the reciprocal is recip_core
+            float s;
+            if (len_sq <= 1.0e12f) s = recip_core(sqrt_core(len_sq));
+            else s = 1.0f / sqrtf(len_sq);
             n0 = n0 * s; n1 = n1 * s; n2 = n2 * s;
         }
         f.wn[0] = n0; f.wn[1] = n1; f.wn[2] = n2;
@@ -325,6 +337,29 @@ __global__ __launch_bounds__(256) void k_selftest_division(unsigned long long se
     (void)div_bad; (void)sqrt_bad;
     atomicAdd(&out[0], (unsigned long long)div_n);
     atomicAdd(&out[2], (unsigned long long)sqrt_n);
+}
+
+// recip_core against the compiler's 1.0f / d for EVERY float d with |d| in [2^-40, 2^83], both signs (2.06e9 operands, a few
+// milliseconds): counted into the same out[0] / out[1] / out[4..7] as the divisions above (n = 1)
+__global__ __launch_bounds__(256) void k_selftest_recip(unsigned long long* __restrict__ out) {
+    const uint32_t span = SWR_RCP_HI_BITS - SWR_DIV_LO_BITS;
+    unsigned n_ok = 0, bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i <= (unsigned long long)span; i += (unsigned long long)gridDim.x * 256ull) {
+#pragma unroll
+        for (uint32_t sign = 0u; sign < 2u; ++sign) {
+            const float d = __uint_as_float((SWR_DIV_LO_BITS + (uint32_t)i) | (sign << 31));
+            const float got = recip_core(d), want = 1.0f / d;
+            ++n_ok;
+            if (__float_as_uint(got) != __float_as_uint(want)) {
+                if (atomicAdd(&out[1], 1ull) == 0ull) {
+                    out[4] = 0x3f800000ull; out[5] = __float_as_uint(d); out[6] = __float_as_uint(got); out[7] = __float_as_uint(want);
+                }
+                ++bad;
+            }
+        }
+    }
+    (void)bad;
+    atomicAdd(&out[0], (unsigned long long)n_ok);
 }
 
 // Rasterizer.Interpolate (public API, Rasterizer.cs:566-640), batched: one thread per weight triple.

@@ -365,6 +365,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
 // the switches fold away); -1 = read them from the draw at run time.
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
+static_assert(SWR_BATCH != 16 || SWR_BATCH_FRAGS != 2048 || sizeof(WaveLdsC<false>) <= 10240, "4 waves per SIMD need <= 10,240 B of LDS per wave");
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
 __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         L.col[p] = c;
         L.z[p] = zz;
     }
-    unsigned n_tested = 0, n_shaded = 0, n_written = 0;
+    unsigned n_tested = 0, n_shaded = 0, n_written = 0;      // per lane, summed over the wave at the end (a count kept on the scalar
+                                                             // side would have to be updated under divergent control flow: per lane again)
     uint32_t carry_key = 0xffffffffu;      // EARLYOUT: (pair, row) of the previous chunk's last fragment ...
     bool carry_dead = false;               // ... and whether that row segment has already hit its `break`
 #ifdef SWR_DEBUG_COUNTERS
@@ -450,6 +452,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 
     // (A rolling batch -- the tail of a batch carried into the next one so that every chunk is full -- was built and measured
     //  twice: chunks -7.7 %, batches +19 %, kernel +4 %.  It lives in the history of this file, commit "Rolling batch ...".)
+#ifdef SWR_ABL_PAD
+    float pad0 = (float)lane, pad1 = pad0 + 1.0f, pad2 = pad0 + 2.0f, pad3 = pad0 + 3.0f;
+#endif
     uint32_t batch_no = 0;
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
@@ -588,6 +593,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
+            const unsigned long long validmask = SWR_BALLOT(g < total);
             // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
             const int hw = pos >> 5, hs = pos & 31;
             const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
@@ -627,21 +633,33 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #ifdef SWR_ABL_NOSELECT
             pix = k & 255;
 #endif
-            // duplicate election: a lane whose pixel was already claimed in this chunk must wait.  Which of two lanes
-            // sharing a pixel loses does not matter: the chunk is cut at the LOWEST loser, so no two lanes before the
-            // cut share a pixel; lane 0 claims first (it seeds the bitmap), so the cut is >= 1.
+            // duplicate election: of the lanes that share a pixel in this chunk all but one must wait.  Which of them
+            // wins does not matter for the result: the chunk is cut at the LOWEST loser, so no two lanes before the cut
+            // share a pixel (a pixel has one winner; two lanes below the cut on one pixel would make one of them a loser
+            // below the cut).  Lane 0 never loses and whoever shares its pixel always does, so the cut is >= 1.
+            // (For speed the LOWER sharer should win -- later cut.  The LDS atomic unit serves lanes in ascending order;
+            //  an election by plain byte stores + read-back, 5 instructions cheaper, lets the HIGHEST lane win and
+            //  halved cfg2's chunks; with a second store round it cost two LDS round trips: cfg3 -1.5 %, cfg2 +6 %.)
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
-            if (lane < 32) L.touched[lane] = (lane == (pix_first & 31)) ? (1u << (pix_first >> 5)) : 0u;
-            SWR_WAVE_LDS_SYNC();      // the seeding store above -> the other lanes' atomics below
-            const uint32_t pbit = 1u << (pix >> 5);
-            bool dup = false;
+            // (every predicate is balloted where its compare is: the ballot of ONE compare is the compare's own lane mask, while a
+            //  ballot of a combined or branch-carried bool is materialised in a VGPR and compared again)
+            unsigned long long dupmask = 0ull;
 #ifndef SWR_ABL_NOELECT
-            if (valid && lane > 0) dup = (atomicOr(&L.touched[pix & 31], pbit) & pbit) != 0u;
+            {
+                // the bitmap is cleared by eight 16-byte stores and every valid lane claims its pixel with one returning atomic:
+                // the lanes of one instruction are served in some order, so exactly one sharer of a pixel sees its bit clear
+                if (lane < 8) *reinterpret_cast<uint4*>(&L.touched[4 * lane]) = make_uint4(0u, 0u, 0u, 0u);
+                SWR_WAVE_LDS_SYNC();      // the clearing store above -> the atomics below
+                const uint32_t pbit = 1u << (pix >> 5);
+                uint32_t before = 0u;
+                if (valid) before = atomicOr(&L.touched[pix & 31], pbit);
+                dupmask = (SWR_BALLOT((before & pbit) != 0u) | SWR_BALLOT(pix == pix_first)) & ~1ull;       // lane 0 never loses
+            }
 #endif
             const uint32_t dflags = __float_as_uint(f1.w);
             const uint32_t draw = dflags & SWR_DRAW_MASK;
             const uint32_t draw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)draw);
-            const unsigned long long stop = SWR_BALLOT(!valid || dup || draw != draw0);
+            const unsigned long long stop = ~validmask | dupmask | SWR_BALLOT(draw != draw0);
             const int cut = stop ? (__ffsll((long long)stop) - 1) : 64;        // >= 1: lane 0 is valid, never dup, own draw
             {
                 const unsigned long long win = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)win_hi) << 32) |
@@ -649,6 +667,10 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
             }
             const bool act = lane < cut;
+#ifdef SWR_ABL_PAD            // tools/ablate.py timing experiment: SWR_ABL_PAD extra VALU instructions per chunk (issue-slack probe)
+#pragma unroll
+            for (int i = 0; i < SWR_ABL_PAD / 4; ++i) { pad0 = pad0 * 1.5f; pad1 = pad1 + 0.25f; pad2 = pad2 * 0.75f; pad3 = pad3 + 1.25f; }
+#endif
 #ifdef SWR_DEBUG_COUNTERS
             ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
 #endif
@@ -791,6 +813,9 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     n_tested = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_tested, lane), 63);
     n_shaded = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_shaded, lane), 63);
     n_written = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_written, lane), 63);
+#ifdef SWR_ABL_PAD
+    if (pad0 + pad1 + pad2 + pad3 == 12345.678f) n_tested += 1u;      // keeps the padding alive
+#endif
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;
         atomicAdd(&ts[0], n_tested); atomicAdd(&ts[1], n_shaded); atomicAdd(&ts[2], n_written);     // no return value: no round trip

@@ -366,14 +366,19 @@ def test_exact_division_core_matches_ieee_division(device):
     """The raster kernel divides by per-pair / per-draw denominators through the division's own mul + 4 fma core on a
     staged refined reciprocal (csrc/swr_device.h).  2^31 operand pairs -- random over the guarded range, quotients next to
     rounding midpoints, guard-boundary exponents / significands, renderer-shaped values -- must give the compiler's
-    correctly rounded quotient bit for bit; likewise the unscaled sqrt core."""
+    correctly rounded quotient bit for bit; likewise the unscaled sqrt core.  The reciprocal core (1 / d: Interpolate's 1 / sum,
+    the normal's 1 / length) is checked on EVERY float d with |d| in [2^-40, 2^83], both signs, in each call."""
+    recip_operands = 2 * (0x69000000 - 0x2B800000 + 1)
     total = {"divisions": 0, "sqrts": 0}
     for seed in (1, 2):
         r = device.selftest_division(1 << 30, seed)
         assert r["division_mismatches"] == 0, f"n={r['bad_n_bits']:#010x} d={r['bad_d_bits']:#010x} got={r['bad_got_bits']:#010x} want={r['bad_want_bits']:#010x}"
         assert r["sqrt_mismatches"] == 0
-        total["divisions"] += r["divisions"]; total["sqrts"] += r["sqrts"]
+        assert r["divisions"] > recip_operands + 900_000_000
+        total["divisions"] += r["divisions"] - recip_operands; total["sqrts"] += r["sqrts"]
     assert total["divisions"] > 2_000_000_000 and total["sqrts"] > 2_000_000_000
+    r = device.selftest_division(0, 3)                      # no sampled pairs: the exhaustive reciprocal sweep alone
+    assert r["divisions"] == recip_operands and r["division_mismatches"] == 0
 
 
 def test_tile_list_overflow_poisons_the_batch_and_is_replayed_exactly(monkeypatch):

@@ -18,7 +18,7 @@ scene = getattr(scenes, %r)()
 dev = Device(0); r = scenes.SceneRenderer(dev, scene)
 for _ in range(3): r.submit_frame(); dev.flush()
 dev.sync(); dev.profile_reset(); dev.profile_enable(True)
-N = 10
+N = int(os.environ.get('ABLATE_N', '10'))
 for _ in range(N): r.submit_frame(); dev.flush()
 p = dev.profile(); print(json.dumps({k: round(v / N, 4) for k, v in p.items() if k.endswith("_ms")}))
 ''' % (ROOT, cfg)
