@@ -41,24 +41,49 @@ struct Frag {
     float wpos[3];
 };
 
+// The per-draw constants a fragment of the reference's programs reads.  k_raster_c keeps one copy in SGPRs and reloads it
+// only when the chunk's draw changes: read through `dp->` in the fragment code they were five dependent scalar-load round
+// trips per 64-fragment chunk (the compiler places each s_load next to its use, behind an s_waitcnt lgkmcnt(0)).
+struct DrawConsts {
+    const uint8_t* tex;
+    int tex_w, tex_h;
+    float tex_wf, tex_hf;
+    float light_direction[3], light_color[3], fog_color[3];
+    float fog_end, fog_den, fog_r1;
+    int program, blend, depth_test;
+};
+__device__ __forceinline__ DrawConsts load_draw_consts(const DrawParams* __restrict__ dp_generic) {
+    // constant address space: nothing writes DrawParams while a raster kernel runs (k_vertex's fog_r1 / fog_den come from an
+    // earlier launch), and with a wave-uniform address this makes every load below an s_load into SGPRs -- as plain global
+    // loads the compiler picks VGPR loads here and then waits for them (and for the texel in flight) in the fragment code
+    typedef const DrawParams __attribute__((address_space(4)))* const_ptr;
+    const const_ptr dp = (const_ptr)(uintptr_t)dp_generic;
+    DrawConsts c;
+    c.tex = (const uint8_t*)dp->tex; c.tex_w = dp->tex_w; c.tex_h = dp->tex_h; c.tex_wf = dp->tex_wf; c.tex_hf = dp->tex_hf;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { c.light_direction[i] = dp->u.light_direction[i]; c.light_color[i] = dp->u.light_color[i]; c.fog_color[i] = dp->u.fog_color[i]; }
+    c.fog_end = dp->u.fog_end; c.fog_den = dp->fog_den; c.fog_r1 = dp->fog_r1;
+    c.program = dp->program; c.blend = dp->blend; c.depth_test = dp->depth_test;
+    return c;
+}
+
 // Renderer.FragmentShader, Renderer.cs:848-860
-__device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, const Frag& f) {
-    const swr_uniforms& u = dp->u;
+__device__ __forceinline__ float4 fs_dust2(const DrawConsts& u, const Frag& f) {
     // everything that does not need the texel first (its load is in flight, see shade_fragment)
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     // (FogEnd - depth) / (FogEnd - FogStart), Renderer.cs:855: the denominator is per draw, its refined reciprocal was
     // computed once by k_vertex (dp->fog_r1, 0 = out of the safe range) -- see div_core in swr_device.h
-    const float fog_num = u.fog_end - f.clip_z, fog_den = dp->fog_den;       // (= u.fog_end - u.fog_start, k_vertex)
-    float fog_q = div_core(fog_num, fog_den, dp->fog_r1);
-    if (!(dp->fog_r1 != 0.0f && div_operand_safe(fog_num))) fog_q = fog_num / fog_den;
+    const float fog_num = u.fog_end - f.clip_z, fog_den = u.fog_den;         // (= u.fog_end - u.fog_start, k_vertex)
+    float fog_q = div_core(fog_num, fog_den, u.fog_r1);
+    if (!(u.fog_r1 != 0.0f && div_operand_safe(fog_num))) fog_q = fog_num / fog_den;
     float fog = math_clamp(fog_q, 0.0f, 1.0f);
     fog = (fog * fog) * (3.0f - 2.0f * fog);
     float s = 0.1f + 0.9f * diffuse;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 #ifndef SWR_ABL_NOTEX          // tools/ablate.py timing experiments only (wrong image by design)
     if (f.texel_loaded) tc = texture_unpack(f.texel);
-    else if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    else if (u.tex) tc = texture_fetch(u.tex, u.tex_w, u.tex_h, f.u, f.v);
 #else
     tc.x = f.u; tc.y = f.v;
 #endif
@@ -72,11 +97,11 @@ __device__ __forceinline__ float4 fs_dust2(const DrawParams* __restrict__ dp, co
 }
 
 // PHONG_4POINT: build-defined, no reference semantics (see oracle/swr_oracle.c fs_phong4 for the formula)
-__device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, const Frag& f) {
+__device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, const DrawConsts& dc, const Frag& f) {
     const swr_uniforms& u = dp->u;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     if (f.texel_loaded) tc = texture_unpack(f.texel);
-    else if (dp->tex) tc = texture_fetch(dp->tex, dp->tex_w, dp->tex_h, f.u, f.v);
+    else if (dc.tex) tc = texture_fetch(dc.tex, dc.tex_w, dc.tex_h, f.u, f.v);
     float base[4] = { f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w };
     // v / |v|: three divisions by one denominator = one refined reciprocal + three division cores (div_core, swr_device.h: the
     // IEEE quotient bit for bit inside its operand range; anything else -- a zero component, a degenerate vector -- takes `/`),
@@ -134,7 +159,7 @@ struct TriVaryings {
 // A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.
 // PHONG = false compiles the build-defined 4-light program out (batches without such a draw): fewer live registers
 template <bool PHONG = true>
-__device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, int program, bool interp,
+__device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, const DrawConsts& dc, int program, bool interp,
                                                  const TriVaryings& V, float w0f, float w1f, float w2f) {
     const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
     const float4 a_clip = V.a_clip, b_clip = V.b_clip, c_clip = V.c_clip;
@@ -175,10 +200,10 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     // interpolation, the normal and the fog term run while it is in flight.  (Bilinear textures fetch in the program.)
     f.texel = 0u; f.texel_loaded = false;
 #ifndef SWR_ABL_NOTEX
-    if (dp->tex && dp->tex_h > 0) {
+    if (dc.tex && dc.tex_h > 0) {
         // global (not generic) address space + 32-bit index: one global_load with the draw's texture pointer as scalar base
         typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
-        f.texel = ((global_u32_ptr)(uintptr_t)dp->tex)[texture_nearest_index(dp->tex_w, dp->tex_h, dp->tex_wf, dp->tex_hf, f.u, f.v)];
+        f.texel = ((global_u32_ptr)(uintptr_t)dc.tex)[texture_nearest_index(dc.tex_w, dc.tex_h, dc.tex_wf, dc.tex_hf, f.u, f.v)];
         f.texel_loaded = true;
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
@@ -216,8 +241,8 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = V.a_wnz;
         if (PHONG) { f.wpos[0] = V.a_wpos[0]; f.wpos[1] = V.a_wpos[1]; f.wpos[2] = V.a_wpos[2]; }
     }
-    if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, f);
-    return fs_dust2(dp, f);
+    if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, dc, f);
+    return fs_dust2(dc, f);
 }
 
 // ---- small utility kernels -------------------------------------------------------------------

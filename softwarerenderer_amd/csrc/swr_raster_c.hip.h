@@ -455,6 +455,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #ifdef SWR_ABL_PAD
     float pad0 = (float)lane, pad1 = pad0 + 1.0f, pad2 = pad0 + 2.0f, pad3 = pad0 + 3.0f;
 #endif
+    DrawConsts dc = {};                    // per-draw constants of draw `dc_draw` (see DrawConsts)
+    uint32_t dc_draw = 0xffffffffu;
     uint32_t batch_no = 0;
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
@@ -676,7 +678,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #endif
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
-            const int f_program = PROG >= 0 ? PROG : cdp->program, f_blend = BLEND >= 0 ? BLEND : cdp->blend, f_dt = DT >= 0 ? DT : cdp->depth_test;
+            if (draw0 != dc_draw) { dc_draw = draw0; dc = load_draw_consts(cdp); }       // wave-uniform: the constants live in SGPRs across chunks
+            const int f_program = PROG >= 0 ? PROG : dc.program, f_blend = BLEND >= 0 ? BLEND : dc.blend, f_dt = DT >= 0 ? DT : dc.depth_test;
             // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
             const bool f_interp = PROG > SWR_PROG_FLAT_COLOR ? true : (__float_as_uint(f1.w) & SWR_FLAG_INTERP) != 0u;
 #ifdef SWR_DEBUG_COUNTERS
@@ -727,7 +730,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #ifdef SWR_ABL_NOSHADE
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                        const float4 src = shade_fragment<PHONG>(cdp, f_program, f_interp,
+                        const float4 src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                                  load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     e_d = d;
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
-                        e_src = shade_fragment<PHONG>(cdp, f_program, f_interp,
+                        e_src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                       load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }
