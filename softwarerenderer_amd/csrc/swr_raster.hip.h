@@ -67,41 +67,33 @@ __device__ __forceinline__ DrawConsts load_draw_consts(const DrawParams* __restr
     return c;
 }
 
-// Renderer.FragmentShader, Renderer.cs:848-860, in two halves: everything that does not need the texel (whose load is in
-// flight, see interpolate_frag), and the rest.  k_raster_c's pipelined loop runs the next chunk's fragment lookup between them.
-__device__ __forceinline__ void fs_dust2_pre(const DrawConsts& u, const Frag& f, float& s, float& fog) {
+// Renderer.FragmentShader, Renderer.cs:848-860
+__device__ __forceinline__ float4 fs_dust2(const DrawConsts& u, const Frag& f) {
+    // everything that does not need the texel first (its load is in flight, see shade_fragment)
     float diffuse = mathf_max(0.25f, dot3(f.wn[0], f.wn[1], f.wn[2],
                                           -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
     // (FogEnd - depth) / (FogEnd - FogStart), Renderer.cs:855: the denominator is per draw, its refined reciprocal was
-    // computed once by k_vertex (fog_r1, 0 = out of the safe range) -- see div_core in swr_device.h
+    // computed once by k_vertex (dp->fog_r1, 0 = out of the safe range) -- see div_core in swr_device.h
     const float fog_num = u.fog_end - f.clip_z, fog_den = u.fog_den;         // (= u.fog_end - u.fog_start, k_vertex)
     float fog_q = div_core(fog_num, fog_den, u.fog_r1);
     if (!(u.fog_r1 != 0.0f && div_operand_safe(fog_num))) fog_q = fog_num / fog_den;
-    fog = math_clamp(fog_q, 0.0f, 1.0f);
+    float fog = math_clamp(fog_q, 0.0f, 1.0f);
     fog = (fog * fog) * (3.0f - 2.0f * fog);
-    s = 0.1f + 0.9f * diffuse;
-}
-__device__ __forceinline__ float4 fs_dust2_post(const DrawConsts& u, float4 color, float s, float fog, bool texel_loaded, uint32_t texel,
-                                                float tu, float tv) {
+    float s = 0.1f + 0.9f * diffuse;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
 #ifndef SWR_ABL_NOTEX          // tools/ablate.py timing experiments only (wrong image by design)
-    if (texel_loaded) tc = texture_unpack(texel);
-    else if (u.tex) tc = texture_fetch(u.tex, u.tex_w, u.tex_h, tu, tv);
+    if (f.texel_loaded) tc = texture_unpack(f.texel);
+    else if (u.tex) tc = texture_fetch(u.tex, u.tex_w, u.tex_h, f.u, f.v);
 #else
-    tc.x = tu; tc.y = tv;
+    tc.x = f.u; tc.y = f.v;
 #endif
-    float4 base = make_float4(color.x * tc.x, color.y * tc.y, color.z * tc.z, color.w * tc.w);
+    float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
     float4 o;
     o.x = nm_lerp(u.fog_color[0], (base.x * s) * u.light_color[0], fog);
     o.y = nm_lerp(u.fog_color[1], (base.y * s) * u.light_color[1], fog);
     o.z = nm_lerp(u.fog_color[2], (base.z * s) * u.light_color[2], fog);
     o.w = base.w;
     return o;
-}
-__device__ __forceinline__ float4 fs_dust2(const DrawConsts& u, const Frag& f) {
-    float s, fog;
-    fs_dust2_pre(u, f, s, fog);
-    return fs_dust2_post(u, f.color, s, fog, f.texel_loaded, f.texel, f.u, f.v);
 }
 
 // PHONG_4POINT: build-defined, no reference semantics (see oracle/swr_oracle.c fs_phong4 for the formula)
@@ -163,18 +155,17 @@ struct TriVaryings {
     float a_wpos[3], b_wpos[3], c_wpos[3];     // PHONG only
 };
 
-// Rasterizer.Interpolate for the varyings `program` reads.
-// A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.  Returns true when `direct` already is the fragment's colour
-// (FLAT_COLOR / GOURAUD have no fragment program beyond the interpolated colour); otherwise fills `f`.
-// PHONG = false compiles the build-defined 4-light program's inputs out (batches without such a draw): fewer live registers
+// Rasterizer.Interpolate for the varyings `program` reads, then the fragment program.
+// A,B,C = outputs[0..2]; w0f..w2f = edge values * invArea.
+// PHONG = false compiles the build-defined 4-light program out (batches without such a draw): fewer live registers
 template <bool PHONG = true>
-__device__ __forceinline__ bool interpolate_frag(const DrawConsts& dc, int program, bool interp,
-                                                 const TriVaryings& V, float w0f, float w1f, float w2f, Frag& f, float4& direct) {
+__device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, const DrawConsts& dc, int program, bool interp,
+                                                 const TriVaryings& V, float w0f, float w1f, float w2f) {
     const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
     const float4 a_clip = V.a_clip, b_clip = V.b_clip, c_clip = V.c_clip;
     const float4 a_col = V.a_col, b_col = V.b_col, c_col = V.c_col;
     const float4 a_uvn = V.a_uvn, b_uvn = V.b_uvn, c_uvn = V.c_uvn;
-    if (simple && !interp) { direct = a_col; return true; }                                          // :622-627
+    if (simple && !interp) return a_col;                                                             // :622-627
 
     // :576-578, true divisions: the denominators are per pair, so their refined reciprocals are staged and each quotient
     // is the division's own mul + 4 fma core (div_core, swr_device.h); operands outside its range take the full sequence
@@ -198,10 +189,10 @@ __device__ __forceinline__ bool interpolate_frag(const DrawConsts& dc, int progr
         w = 1.0f / inv_sum;
     }
 #define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
+    Frag f;
     if (simple) {
-        direct = make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
-                             SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));   // interp (see above)
-        return true;
+        return make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
+                           SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));     // interp (see above)
     }
     f.u = SWR_PERSP(a_uvn.x, b_uvn.x, c_uvn.x);
     f.v = SWR_PERSP(a_uvn.y, b_uvn.y, c_uvn.y);
@@ -250,43 +241,8 @@ __device__ __forceinline__ bool interpolate_frag(const DrawConsts& dc, int progr
         f.wn[0] = a_uvn.z; f.wn[1] = a_uvn.w; f.wn[2] = V.a_wnz;
         if (PHONG) { f.wpos[0] = V.a_wpos[0]; f.wpos[1] = V.a_wpos[1]; f.wpos[2] = V.a_wpos[2]; }
     }
-    return false;
-}
-
-// Rasterizer.Interpolate, then the fragment program
-template <bool PHONG = true>
-__device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, const DrawConsts& dc, int program, bool interp,
-                                                 const TriVaryings& V, float w0f, float w1f, float w2f) {
-    Frag f;
-    float4 direct;
-    if (interpolate_frag<PHONG>(dc, program, interp, V, w0f, w1f, w2f, f, direct)) return direct;
     if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, dc, f);
     return fs_dust2(dc, f);
-}
-
-// The same in two steps for k_raster_c's pipelined loop (programs of the reference only, PHONG = false): shade_begin runs
-// Interpolate and everything of the program that does not need the texel, whose load it leaves in flight; shade_finish the rest.
-struct PendingFrag {
-    float4 color;          // interpolated colour -- or the finished fragment colour of FLAT_COLOR / GOURAUD
-    float s, fog;          // fs_dust2_pre
-    float u, v;            // bilinear textures fetch in shade_finish
-    uint32_t texel;
-    bool texel_loaded;     // wave-uniform (a property of the draw)
-};
-__device__ __forceinline__ PendingFrag shade_begin(const DrawConsts& dc, int program, bool interp,
-                                                   const TriVaryings& V, float w0f, float w1f, float w2f) {
-    Frag f;
-    float4 direct;
-    PendingFrag P;
-    P.s = 0.0f; P.fog = 0.0f; P.u = 0.0f; P.v = 0.0f; P.texel = 0u; P.texel_loaded = false;
-    if (interpolate_frag<false>(dc, program, interp, V, w0f, w1f, w2f, f, direct)) { P.color = direct; return P; }
-    fs_dust2_pre(dc, f, P.s, P.fog);
-    P.color = f.color; P.u = f.u; P.v = f.v; P.texel = f.texel; P.texel_loaded = f.texel_loaded;
-    return P;
-}
-__device__ __forceinline__ float4 shade_finish(const DrawConsts& dc, int program, const PendingFrag& P) {
-    if (program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD) return P.color;
-    return fs_dust2_post(dc, P.color, P.s, P.fog, P.texel_loaded, P.texel, P.u, P.v);
 }
 
 // ---- small utility kernels -------------------------------------------------------------------

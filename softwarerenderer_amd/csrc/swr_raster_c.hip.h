@@ -457,32 +457,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #endif
     DrawConsts dc = {};                    // per-draw constants of draw `dc_draw` (see DrawConsts)
     uint32_t dc_draw = 0xffffffffu;
-    // Software pipeline over chunks (kernels of the reference's programs, triangles, no row early-out).  A wave's time per
-    // chunk is a chain of dependent latencies, the longest being the texel gather, and four waves per SIMD do not cover it.
-    // So a chunk is shaded in two steps: shade_begin (replay, depth test, Interpolate, texel load issued, the texel-independent
-    // part of the program) leaves a PENDING fragment per lane; the next chunk's lookup / election / replay -- which touch
-    // neither the tile's colour nor its depth -- run while the texel is in flight; shade_finish + blend + store follow, BEFORE
-    // the next chunk's depth test reads the tile (program order per pixel is kept: finish(i-1) precedes begin(i)).
-    // The pending state survives batch boundaries (staging does not touch it; hi-Z then sees a tile minimum that lacks the
-    // pending depth writes: lower, i.e. more conservative).  It is drained before the draw constants change and at the end.
-    constexpr bool PIPE = !LINES && !PHONG && !EARLYOUT;
-    PendingFrag pend = {};
-    bool pend_on = false;                  // this lane holds a pending fragment
-    int pend_pix = 0;
-    float pend_d = 0.0f;
-    auto finish_pending = [&]() {
-        if (PIPE && pend_on) {
-            const int p_program = PROG >= 0 ? PROG : dc.program, p_blend = BLEND >= 0 ? BLEND : dc.blend, p_dt = DT >= 0 ? DT : dc.depth_test;
-            const float4 src = shade_finish(dc, p_program, pend);                                     // :507-509
-            if (src.w > 0.0f) {                                                                           // :511
-                const float4 dst = L.col[pend_pix];
-                L.col[pend_pix] = blend(src, dst, p_blend);                                               // :513-515
-                if (p_dt != SWR_DEPTH_DISABLED) L.z[pend_pix] = pend_d;                                   // :517-518
-                ++n_written;
-            }
-            pend_on = false;
-        }
-    };
     uint32_t batch_no = 0;
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
@@ -704,60 +678,17 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #endif
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
-            if (draw0 != dc_draw) {                // wave-uniform: the constants live in SGPRs across chunks
-                finish_pending();                  // (the pending fragments belong to the old draw)
-                dc_draw = draw0; dc = load_draw_consts(cdp);
-            }
+            if (draw0 != dc_draw) { dc_draw = draw0; dc = load_draw_consts(cdp); }       // wave-uniform: the constants live in SGPRs across chunks
             const int f_program = PROG >= 0 ? PROG : dc.program, f_blend = BLEND >= 0 ? BLEND : dc.blend, f_dt = DT >= 0 ? DT : dc.depth_test;
             // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
             const bool f_interp = PROG > SWR_PROG_FLAT_COLOR ? true : (__float_as_uint(f1.w) & SWR_FLAG_INTERP) != 0u;
 #ifdef SWR_DEBUG_COUNTERS
             int dbg_nrow = 0, dbg_ncol = 0;
 #endif
-            if (PIPE) {
-                // step 1 of this chunk that needs nothing of the tile: the add-chain replay and the depth value
-                float w0f = 0.0f, w1f = 0.0f, w2f = 0.0f, d = 0.0f;
-                if (act) {
-                    const float d0 = f1.x, d1 = f1.y, d2 = f1.z;
-                    const uint32_t fs = __float_as_uint(f2.w);
-                    float w0 = f0.x, w1 = f0.y, w2 = f0.z;
-                    const float inv_area = f0.w;
-#ifdef SWR_ABL_NOREPLAY
-                    const int nrow = 0, ncol = 0; asm volatile("" :: "v"(fs));
-#else
-                    const int nrow = (pix >> 4) - (int)(fs >> 8), ncol = (pix & 15) - (int)(fs & 0xffu);
-#endif
-#ifdef SWR_DEBUG_COUNTERS
-                    dbg_nrow = nrow; dbg_ncol = ncol;
-#endif
-                    {
-                        const int q = nrow >> 2, qi = max(q, 1) - 1;
-                        const float t0r = L.rowtab[qi][0][t], t1r = L.rowtab[qi][1][t], t2r = L.rowtab[qi][2][t];
-                        if (q > 0) { w0 = t0r; w1 = t1r; w2 = t2r; }
-                        const int rem = nrow & 3;
-                        for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
-                    }
-                    for (int i = 0; i < ncol; ++i) { w0 += f2.x; w1 += f2.y; w2 += f2.z; }                // :527-529
-                    w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
-                    d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
-                }
-                // the previous chunk's fragments: texel wait, rest of the program, blend, tile store
-                finish_pending();
-                // step 2: depth test against the tile as the previous chunk left it, Interpolate, texel load issued
-                if (act && depth_func(f_dt, d, L.z[pix])) {                                               // :505
-                    ++n_shaded;
-#ifdef SWR_ABL_NOSHADE
-                    pend = PendingFrag{}; pend.color = make_float4(w0f, w1f, w2f, 1.0f);
-#else
-                    pend = shade_begin(dc, f_program, f_interp, load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
-#endif
-                    pend_on = true; pend_pix = pix; pend_d = d;
-                }
-            }
             bool e_pass = false, e_alpha = false;          // EARLYOUT: results held until the row kills are known
             float e_d = 0.0f;
             float4 e_src = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!PIPE && act) {
+            if (act) {
                 const float d0 = f1.x, d1 = f1.y, d2 = f1.z;
                 const uint32_t fs = __float_as_uint(f2.w);
                 const bool is_line = LINES && (dflags & SWR_FLAG_LINE) != 0u;
@@ -870,7 +801,6 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         }
     }
 
-    finish_pending();
     // ---- write back: each wave store covers 4 rows x 256 B (colour) / 4 rows x 64 B (Z) ----
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
