@@ -671,7 +671,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const bool act = lane < cut;
 #ifdef SWR_ABL_PAD            // tools/ablate.py timing experiment: SWR_ABL_PAD extra VALU instructions per chunk (issue-slack probe)
 #pragma unroll
+#ifdef SWR_ABL_PAD_FMA
+            for (int i = 0; i < SWR_ABL_PAD / 4; ++i) { pad0 = __builtin_fmaf(pad0, 1.5f, pad1); pad1 = __builtin_fmaf(pad1, 0.25f, pad2);
+                                                        pad2 = __builtin_fmaf(pad2, 0.75f, pad3); pad3 = __builtin_fmaf(pad3, 1.25f, pad0); }
+#else
             for (int i = 0; i < SWR_ABL_PAD / 4; ++i) { pad0 = pad0 * 1.5f; pad1 = pad1 + 0.25f; pad2 = pad2 * 0.75f; pad3 = pad3 + 1.25f; }
+#endif
 #endif
 #ifdef SWR_DEBUG_COUNTERS
             ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
