@@ -8,5 +8,6 @@ for c in cfg2 cfg4 cfg5; do
   python3 tools/summarize_rocprof.py ${OUT}_$c gpurun_out/prof_${TAG}_$c "" "" gpurun_out/bench_${TAG}_$c.json || exit 1
 done
 cp gpurun_out/sq_counters_$TAG.txt profiles/${OUT}_sq_counters.txt
-tail -1 gpurun_out/bench_$TAG.json > profiles/${OUT}_bench_with_cpu.json
+# (the bench line of the profile round was printed before this script refreshed the traffic file: run `python bench.py` once more on
+#  the GPU afterwards and store its line as profiles/OUT_bench_with_cpu.json -- it then carries roofline.traffic)
 python3 bench.py --print-src-hash; grep -o '"csrc_sha256": "[0-9a-f]*"' profiles/*_traffic.json
