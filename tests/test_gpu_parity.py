@@ -180,6 +180,34 @@ def _random_scene(seed):
                         near_clip=float(rng.choice([0.1, 0.5, 0.01])))
 
 
+@pytest.mark.parametrize("mixed_states", [False, True])
+def test_every_draw_has_its_own_uniforms_and_texture(device, mixed_states):
+    """One flush, nine overlapping draws, each with its own uniform block (light direction / colour, fog colour / range -- one
+    range degenerate, one outside the division core's guard), its own texture (different sizes, one draw untextured).  The raster
+    kernel holds the per-draw constants in SGPRs and reloads them when the draw changes inside a tile's stream (DrawConsts):
+    with one program the state-specialised kernel runs; `mixed_states` also varies program / blend / depth test (generic kernel)."""
+    from softwarerenderer_amd.rasterizer import Program, BlendMode, DepthTest
+    rng = np.random.default_rng(5)
+    s = scenes.cfg3(300, 220, (3, 3), (14, 10), tex_size=32, seed=9)
+    s.textures = [scenes.random_texture(n, 40 + n, alpha=None if n % 2 else 255) for n in (32, 7, 64, 1, 19)]
+    fog_ranges = [(1.0, 25.0), (0.5, 6.0), (3.0, 3.0), (2.0, 2.0 + 1e-20), (10.0, 4.0), (0.0, 1e15), (1.0, 25.0), (5.0, 40.0), (1.0, 2.0)]
+    for i, d in enumerate(s.draws):
+        u = scenes.default_uniforms()
+        ld = rng.normal(size=3); ld /= np.linalg.norm(ld)
+        u.light_direction[:] = [float(x) for x in ld]
+        u.light_color[:] = [float(x) for x in rng.uniform(0.2, 1.5, 4)]
+        u.fog_color[:] = [float(x) for x in rng.uniform(0.0, 1.0, 4)]
+        u.fog_start, u.fog_end = fog_ranges[i]
+        d.uniforms = u
+        d.texture = None if i == 4 else i % len(s.textures)
+        if mixed_states:
+            d.program = [Program.Dust2LambertFog, Program.Gouraud, Program.FlatColor][i % 3]
+            d.blend = list(BlendMode)[i % 4]
+            d.depth_test = [DepthTest.LessEqual, DepthTest.Less, DepthTest.Always][i % 3]
+    s.name = "per_draw_constants" + ("_mixed" if mixed_states else "")
+    run_both(device, s)
+
+
 @pytest.mark.parametrize("seed", range(60))
 def test_randomised_scenes(device, seed):
     run_both(device, _random_scene(1000 + seed))
