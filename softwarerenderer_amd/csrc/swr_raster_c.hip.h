@@ -592,13 +592,23 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         SWR_WAVE_LDS_SYNC();
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
+#ifndef SWR_NO_HEAD_PREFETCH
+        // the three head words of a chunk's window are fetched one chunk ahead (as soon as the previous chunk's cut is known), so the
+        // first link of the lookup's dependent chain -- an LDS round trip -- is off the chunk's critical path
+        uint32_t hn0 = L.head[0], hn1 = L.head[1], hn2 = L.head[2];
+#endif
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
             const unsigned long long validmask = SWR_BALLOT(g < total);
             // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
-            const int hw = pos >> 5, hs = pos & 31;
+            const int hs = pos & 31;
+#ifndef SWR_NO_HEAD_PREFETCH
+            const uint32_t h0 = hn0, h1 = hn1, h2 = hn2;
+#else
+            const int hw = pos >> 5;
             const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
+#endif
             const uint32_t win_lo = __builtin_amdgcn_alignbit(h1, h0, hs), win_hi = __builtin_amdgcn_alignbit(h2, h1, hs);
             const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
             const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
@@ -670,6 +680,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
             }
             const bool act = lane < cut;
+#ifndef SWR_NO_HEAD_PREFETCH
+            {   // (the head array has two spare words behind the last position: reading past the batch's end is in bounds)
+                const int hw_next = (pos + cut) >> 5;
+                hn0 = L.head[hw_next]; hn1 = L.head[hw_next + 1]; hn2 = L.head[hw_next + 2];
+            }
+#endif
 #ifdef SWR_ABL_PAD            // tools/ablate.py timing experiment: SWR_ABL_PAD extra VALU instructions per chunk (issue-slack probe)
 #pragma unroll
 #ifdef SWR_ABL_PAD_FMA
