@@ -593,9 +593,22 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
 #ifndef SWR_NO_HEAD_PREFETCH
-        // the three head words of a chunk's window are fetched one chunk ahead (as soon as the previous chunk's cut is known), so the
-        // first link of the lookup's dependent chain -- an LDS round trip -- is off the chunk's critical path
+        // The first two links of the lookup's dependent chain are taken off the chunk's critical path by running them one chunk
+        // ahead: the three head words of the next window are fetched as soon as this chunk's cut is known, and between this
+        // chunk's chain replay and its shading each lane's next pair is computed from them and that pair's word prefix counts
+        // and stream position are fetched (`lookup_ahead`).  The next chunk then starts with its mask-word read.
         uint32_t hn0 = L.head[0], hn1 = L.head[1], hn2 = L.head[2];
+        int t_n = 0;                           // next chunk: pair of this lane's fragment ...
+        uint4 wp_n = make_uint4(0u, 0u, 0u, 0u);   // ... its word prefix counts ...
+        uint32_t pre_n = 0u;                   // ... and the stream position of its first fragment
+        auto lookup_ahead = [&](int pos_n) {
+            const int hs_n = pos_n & 31;
+            const uint32_t wl = __builtin_amdgcn_alignbit(hn1, hn0, hs_n), wh = __builtin_amdgcn_alignbit(hn2, hn1, hs_n);
+            t_n = t0 + (int)__builtin_amdgcn_mbcnt_hi(wh, __builtin_amdgcn_mbcnt_lo(wl, 0u));
+            wp_n = *reinterpret_cast<const uint4*>(&L.wpre[t_n][0]);
+            pre_n = __float_as_uint(L.stage[3][t_n].w);
+        };
+        lookup_ahead(0);
 #endif
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
@@ -610,14 +623,26 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
 #endif
             const uint32_t win_lo = __builtin_amdgcn_alignbit(h1, h0, hs), win_hi = __builtin_amdgcn_alignbit(h2, h1, hs);
+#ifndef SWR_NO_HEAD_PREFETCH
+            const int t = t_n;
+#else
             const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
+#endif
             const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
+#ifndef SWR_NO_HEAD_PREFETCH
+            int k = valid ? g - (int)pre_n : 0;
+#else
             int k = valid ? g - (int)__float_as_uint(f3.w) : 0;
+#endif
             // k-th covered pixel of pair t in row-major order: the mask word by a 16-bit-field compare against the
             // word prefix counts, then a 5-level selection inside the word
             int pix;
             {
+#ifndef SWR_NO_HEAD_PREFETCH
+                const uint4 wp = wp_n;
+#else
                 const uint4 wp = *reinterpret_cast<const uint4*>(&L.wpre[t][0]);
+#endif
                 const uint32_t kk = ((uint32_t)k | ((uint32_t)k << 16)) | 0x80008000u;
                 const int nle = __popc((kk - wp.x) & 0x80008000u) + __popc((kk - wp.y) & 0x80008000u) +
                                 __popc((kk - wp.z) & 0x80008000u) + __popc((kk - wp.w) & 0x80008000u);    // fields <= k, >= 1
@@ -710,11 +735,11 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             bool e_pass = false, e_alpha = false;          // EARLYOUT: results held until the row kills are known
             float e_d = 0.0f;
             float4 e_src = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool is_line = LINES && (dflags & SWR_FLAG_LINE) != 0u;
+            float w0f = 0.0f, w1f = 0.0f, w2f = 0.0f, d = 0.0f;
             if (act) {
                 const float d0 = f1.x, d1 = f1.y, d2 = f1.z;
                 const uint32_t fs = __float_as_uint(f2.w);
-                const bool is_line = LINES && (dflags & SWR_FLAG_LINE) != 0u;
-                float w0f, w1f, w2f, d;
                 if (is_line) {
                     // DrawLine fragment, Rasterizer.cs:299-322: weights (1-t, t, 0) on outputs[0], outputs[1], outputs[0]
                     float t;
@@ -745,6 +770,11 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }
+            }
+#ifndef SWR_NO_HEAD_PREFETCH
+            lookup_ahead(pos + cut);           // all lanes; its LDS reads return during the shading below
+#endif
+            if (act) {
                 if (!EARLYOUT) {
                     if (depth_func(f_dt, d, L.z[pix])) {                                                   // :505 / :318
                         ++n_shaded;
