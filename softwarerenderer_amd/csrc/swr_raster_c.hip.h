@@ -677,8 +677,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const uint32_t fs_early = __float_as_uint(f2.w);
             const int nrow_e = (pix >> 4) - (int)(fs_early >> 8);          // (lines, invalid lanes: any value; q stays in 0..3)
             const int q_e = nrow_e >> 2, qi_e = max(q_e, 1) - 1;
-            const float t0r_e = L.rowtab[qi_e][0][t], t1r_e = L.rowtab[qi_e][1][t], t2r_e = L.rowtab[qi_e][2][t];
-            const float z_old = L.z[pix];
+            // (not in the row-early-out kernels: they are at the register limit, and three spilled dwords cost more than the round trip)
+            float t0r_e = 0.0f, t1r_e = 0.0f, t2r_e = 0.0f, z_old = 0.0f;
+            if (!EARLYOUT) {
+                t0r_e = L.rowtab[qi_e][0][t]; t1r_e = L.rowtab[qi_e][1][t]; t2r_e = L.rowtab[qi_e][2][t];
+                z_old = L.z[pix];
+            }
             // duplicate election: of the lanes that share a pixel in this chunk all but one must wait.  Which of them
             // wins does not matter for the result: the chunk is cut at the LOWEST loser, so no two lanes before the cut
             // share a pixel (a pixel has one winner; two lanes below the cut on one pixel would make one of them a loser
@@ -770,6 +774,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     // rows: from the nearest staged row start (rowtab: rows 4, 8, 12 of the pair), at most 3 steps
                     {
                         const int q = nrow >> 2;
+                        if (EARLYOUT) { t0r_e = L.rowtab[qi_e][0][t]; t1r_e = L.rowtab[qi_e][1][t]; t2r_e = L.rowtab[qi_e][2][t]; }
                         if (q > 0) { w0 = t0r_e; w1 = t1r_e; w2 = t2r_e; }          // (read ahead of the election, see there)
                         const int rem = nrow & 3;
                         for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
@@ -802,7 +807,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     }
                 } else {
                     e_d = d;
-                    e_pass = depth_func(f_dt, d, z_old);
+                    e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
                         e_src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                       load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
