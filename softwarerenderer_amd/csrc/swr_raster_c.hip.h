@@ -18,6 +18,9 @@
 //   stages what fragments need in LDS (per-fragment gathers through the vector L1 were the first bound), pairs that
 //   provably fail the depth test everywhere are dropped against the tile's minimum stored depth (hi-Z), and tiles
 //   are dispatched heaviest first (k_tile_hist / k_tile_place in swr_binning.hip.h).
+//   A wave's time per chunk is a chain of dependent LDS / memory round trips that four waves per SIMD (LDS: 10 KB per wave) do
+//   not cover, so the links that can run early do: the next window's head words are read at the cut, each lane's next pair and
+//   that pair's prefix counts between replay and shading, the row-start table and stored depth ahead of the election's atomic.
 #pragma once
 #include "swr_device.h"
 #include "swr_raster.hip.h"
@@ -37,7 +40,7 @@ namespace swr {
 #define SWR_WAVE_LDS_SYNC() ((void)0)
 
 // wave64 ballot straight from a bool: HIP's __ballot(int) first materialises the predicate as 0 / 1 in a VGPR and compares it
-// with zero again (two VALU instructions per use in a VALU-bound kernel); the builtin takes the condition mask as it is
+// with zero again (two VALU instructions per use); the builtin takes the condition mask as it is
 #define SWR_BALLOT(cond) __builtin_amdgcn_ballot_w64((bool)(cond))
 
 // Inclusive prefix sum over the wave, on the DPP path (no LDS round trips): Hillis-Steele inside each row of 16 lanes
