@@ -268,7 +268,7 @@ def main():
     dev.reset_stats()
     if not args.no_profile_events:
         dev.profile_reset()
-        dev.profile_enable(2)          # hipEvents around the dominant kernel only: every event pair costs ~10 us of stream time
+        dev.profile_enable(3)          # hipEvents around the dominant kernel of every 4th step: an event pair costs ~10 us of stream time
     barrier()
     state["ev"] = []
     t0 = time.perf_counter()
@@ -353,6 +353,7 @@ def main():
                 "traffic_unit": "GB per launch = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this build (null: none for this build); algorithmic = written fragments x 20 B",
                 "algorithmic_gb_per_launch": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / 1e9, 4),
                 "kernel_ms": round(raster_ms, 4),
+                "kernel_launches_timed": int(prof["raster_launches"]),      # every 4th launch of the timed region carries an event pair
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": stage_ms,
             }

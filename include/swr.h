@@ -219,7 +219,8 @@ int  swr_interpolate(swr_context* ctx, const float* verts60, const float* w, int
 /* counters / profiling ------------------------------------------------------------------------ */
 int  swr_get_stats(swr_context* ctx, swr_stats* out);   /* syncs */
 int  swr_reset_stats(swr_context* ctx);
-int  swr_profile_enable(swr_context* ctx, int on);       /* 0 off; 1 hipEvent pairs around every stage of a flush; 2 around the raster kernel only */
+int  swr_profile_enable(swr_context* ctx, int on);       /* 0 off; 1 hipEvent pairs around every stage of a flush; 2 around the raster kernel only;
+                                                           * 3 around the raster kernel of every 4th flush (a pair costs about 10 us of stream time) */
 int  swr_profile_get(swr_context* ctx, swr_profile* out); /* syncs */
 int  swr_profile_reset(swr_context* ctx);
 int  swr_device_name(swr_context* ctx, char* buf, int buflen);

@@ -143,7 +143,8 @@ class Device:
         self._ck(self._lib.swr_reset_stats(self._ctx))
 
     def profile_enable(self, on):
-        """False/0 off, True/1 events around every stage, 2 around the raster kernel only (cheapest)."""
+        """False/0 off, True/1 events around every stage, 2 around the raster kernel only, 3 around the raster kernel of every
+        4th flush (an event pair costs about 10 us of stream time)."""
         self._ck(self._lib.swr_profile_enable(self._ctx, int(on)))
 
     def profile(self) -> dict:
