@@ -328,6 +328,14 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_WINDOW
 #define SWR_WINDOW 32                          // candidate pairs examined per batch (<= 64)
 #endif
+// The kernels that carry the 4-light program's extra varyings (PHONG: 16 instead of 13 staged rows per pair) would need 10,960 B
+// with 16 pairs: 14 waves per CU instead of 16.  They stage 12 pairs (9,600 B): cfg4's raster kernel -8 % (13 pairs: -6 %).
+#ifndef SWR_BATCH_PHONG
+#define SWR_BATCH_PHONG 12
+#endif
+#ifndef SWR_WINDOW_PHONG
+#define SWR_WINDOW_PHONG 24
+#endif
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
@@ -338,15 +346,17 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
     static constexpr int NQ = PHONG ? 16 : 13;
+    static constexpr int BATCH = PHONG ? SWR_BATCH_PHONG : SWR_BATCH;       // pairs staged per batch
+    static constexpr int WINDOW = PHONG ? SWR_WINDOW_PHONG : SWR_WINDOW;    // candidate pairs examined per batch
     float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
     float z[256];
-    float4 stage[NQ][SWR_BATCH];     // batch (non-empty pairs only, compacted): per-pair fragment inputs
-    uint32_t mask[SWR_BATCH][8];     // coverage masks
-    uint32_t wpre[SWR_BATCH][4];     // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
+    float4 stage[NQ][BATCH];         // batch (non-empty pairs only, compacted): per-pair fragment inputs
+    uint32_t mask[BATCH][8];         // coverage masks
+    uint32_t wpre[BATCH][4];         // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
     uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (first - 1) set for every pair t >= 1 (first = its stream position): pair of fragment g = #bits below g
     uint32_t touched[32];            // chunk duplicate election: pixel p claimed <=> bit (p >> 5) of word (p & 31) -- neighbouring
                                      // pixels (the usual content of a chunk) fall into different words: no same-address atomics
-    float rowtab[3][3][SWR_BATCH];   // [q][edge][pair]: the pair's edge values at the start of its rows 4, 8, 12 (q = 0, 1, 2), i.e.
+    float rowtab[3][3][BATCH];       // [q][edge][pair]: the pair's edge values at the start of its rows 4, 8, 12 (q = 0, 1, 2), i.e.
                                      // the reference's row chain (Rasterizer.cs:532-534) run once per pair at staging: a fragment's
                                      // row replay is then at most 3 add steps from the nearest entry instead of up to 15
 };
@@ -369,6 +379,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // the switches fold away); -1 = read them from the draw at run time.
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
 static_assert(SWR_BATCH != 16 || SWR_BATCH_FRAGS != 2048 || sizeof(WaveLdsC<false>) <= 10240, "4 waves per SIMD need <= 10,240 B of LDS per wave");
+static_assert(SWR_BATCH_PHONG != 12 || SWR_BATCH_FRAGS != 2048 || sizeof(WaveLdsC<true>) <= 10240, "4 waves per SIMD need <= 10,240 B of LDS per wave");
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
 __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
@@ -416,14 +427,15 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     const int W = a.fp.width, H = a.fp.height;
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
 
-    // A sliding window of SWR_WINDOW candidate pairs (lane i holds entry base + i of the tile list: references and
-    // count, fetched while the previous batch is rasterised).  Each batch stages the first SWR_BATCH candidates that
+    // A sliding window of WINDOW candidate pairs (lane i holds entry base + i of the tile list: references and
+    // count, fetched while the previous batch is rasterised).  Each batch stages the first BATCH candidates that
     // survive (non-empty, not hidden by hi-Z) and consumes the list up to the last of them, so batches are full
     // although a third of the candidates drops out.
     uint4 ref_w = make_uint4(0u, 0u, 0u, 0u);
     int cnt_w = 0;
     float zb_w = 0.0f;                     // hi-Z bound of the entry (k_cover)
-    if (lane < SWR_WINDOW && (uint32_t)lane < n) {
+    constexpr int BATCH = WaveLdsC<PHONG>::BATCH, WINDOW = WaveLdsC<PHONG>::WINDOW;
+    if (lane < WINDOW && (uint32_t)lane < n) {
         ref_w = a.pair_refs[start + (uint32_t)lane];
         const uint2 pi = info[start + (uint32_t)lane];
         cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);          // cnt_w keeps k_cover's SWR_INFO_SIMPLE bit (the sign)
@@ -462,11 +474,11 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     uint32_t dc_draw = 0xffffffffu;
     uint32_t batch_no = 0;
     for (uint32_t base = 0; base < n; ++batch_no) {
-        // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first SWR_BATCH survivors
+        // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first BATCH survivors
         //      of the window are staged in LDS ----
         const uint32_t pidx = start + base + (uint32_t)lane;
         const uint4 ref = ref_w;
-        const bool in_window = lane < SWR_WINDOW && base + (uint32_t)lane < n;
+        const bool in_window = lane < WINDOW && base + (uint32_t)lane < n;
         const bool simple_in = cnt_w < 0;                                // SWR_INFO_SIMPLE
         const int cnt_in = in_window ? (cnt_w & 0x7fffffff) : 0;
         int cnt = cnt_in;
@@ -488,15 +500,15 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             if (cnt > 0 && zmin > SWR_FLOAT_MINVALUE && zb_w < zmin) cnt = 0;
 #endif
         }
-        // take the first survivors -- at most SWR_BATCH pairs and SWR_BATCH_FRAGS fragments (the running sum is monotone, so the
+        // take the first survivors -- at most BATCH pairs and SWR_BATCH_FRAGS fragments (the running sum is monotone, so the
         // taken set is a prefix of the survivors; the first one always fits); the list is consumed up to the first survivor left out
         int consumed;
         const int cscan = wave_incl_scan(cnt, lane);
         {
             const unsigned long long surv = SWR_BALLOT(cnt > 0);
             const int rank = __popcll(surv & ((1ull << lane) - 1ull));
-            const unsigned long long left_out = SWR_BALLOT(cnt > 0 && (rank >= SWR_BATCH || cscan > SWR_BATCH_FRAGS));
-            consumed = left_out ? __ffsll((long long)left_out) - 1 : min(SWR_WINDOW, (int)(n - base));
+            const unsigned long long left_out = SWR_BALLOT(cnt > 0 && (rank >= BATCH || cscan > SWR_BATCH_FRAGS));
+            consumed = left_out ? __ffsll((long long)left_out) - 1 : min(WINDOW, (int)(n - base));
             if (lane >= consumed) cnt = 0;
         }
         const int cnt_seen = lane < consumed ? cnt_in : 0;
@@ -515,7 +527,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const float z2 = __int_as_float(__shfl(__float_as_int(zb_w), src));
             ref_w = r2; cnt_w = c2; zb_w = z2;
             const uint32_t e = base + (uint32_t)lane;
-            if (lane >= SWR_WINDOW - consumed && lane < SWR_WINDOW && e < n) {
+            if (lane >= WINDOW - consumed && lane < WINDOW && e < n) {
                 ref_w = a.pair_refs[start + e];
                 const uint2 pi = info[start + e];
                 cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
@@ -833,7 +845,7 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 // "any failure to my left" over lanes; a segment cut by the chunk boundary carries its state over.
                 bool killed = false;
                 const bool none = f_blend == SWR_BLEND_NONE;                       // uniform: a chunk holds one draw
-                const uint32_t key = ((batch_no * (uint32_t)SWR_BATCH + (uint32_t)t) << 4) | (uint32_t)(pix >> 4);   // unique per (pair, row)
+                const uint32_t key = ((batch_no * (uint32_t)BATCH + (uint32_t)t) << 4) | (uint32_t)(pix >> 4);   // unique per (pair, row)
                 if (none) {
                     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
                     const bool head = act && (lane == 0 || key != prev);
