@@ -58,7 +58,9 @@ def main():
                     help="N>1: what reaches rank 0 per frame and how -- rgb32f = the present payload of MainWindow.OnRender "
                          "(Vector4 -> Vector3 flatten, 12 B/pixel) by an RCCL gather, rgba32f = the raw colour buffer (16 B/pixel) "
                          "by an RCCL gather, p2p = the rgb32f payload stored by every rank's flatten kernel straight into rank 0's "
-                         "frame through a peer-mapped (IPC) pointer over xGMI: no collective in the data path, one barrier per frame")
+                         "frame through a peer-mapped (IPC) pointer over xGMI: no collective in the data path; the ranks meet at a barrier "
+                         "every 32 frames and at the ends of the warm-up / timed regions (checkpoint()), not per frame: between checkpoints "
+                         "rank 0's frame is a landing zone that nobody reads")
     ap.add_argument("--stripes", type=int, default=0,
                     help="N>1: instead of one contiguous band per rank, interleave stripes of this many tile rows round-robin over "
                          "the ranks (swr_set_band_interleaved; load balance for clustered scenes).  RCCL gather modes only.")
@@ -71,12 +73,13 @@ def main():
         print(kernel_source_hash())
         return
 
+    rc = launch_ranks_if_needed(args, sys.argv[1:])
+    if rc is not None:
+        raise SystemExit(rc)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
     import torch                      # plumbing: device memory for the bands, streams, RCCL
@@ -212,15 +215,26 @@ def main():
             dist.barrier()
         dev.sync()
         r = dev.replay_count()
-        if world > 1 and r != state["replays"] and state["last_k"] is not None:
-            state["replays"] = r
+        replayed = world > 1 and r != state["replays"]
+        state["replays"] = r
+        if world > 1 and not args.fake_world:
+            # the re-send below is a collective in the RCCL modes and a store into rank 0's frame in p2p mode: every rank has to
+            # know whether ANY rank replayed, take part, and meet again before rank 0 may read its frame
+            flag = torch.tensor([1 if replayed else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            replayed = bool(flag.item())
+        if replayed and state["last_k"] is not None:
             k = state["last_k"]
             window.BindFramebuffer(color_t[k].data_ptr(), depth_t[k].data_ptr())
             w = send_band(k)
             if w is not None:
                 w.wait()
             torch.cuda.current_stream().synchronize()
+            if xfer is not None:
+                xfer.synchronize()
             state["resent"] += 1
+            if not args.fake_world:
+                dist.barrier()
         state["since_check"] = 0
 
     def barrier():
@@ -323,8 +337,11 @@ def main():
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
                        "parallelism": "1 GPU" if world == 1 else (f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0" if not p2p else
-                                      f"{world} tile-row bands, each rank's flatten kernel stores its rgb32f band into rank 0's frame through a peer-mapped pointer (xGMI), one barrier per frame")
-                                      + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")},
+                                      f"{world} tile-row bands, each rank's flatten kernel stores its rgb32f band into rank 0's frame through a peer-mapped pointer (xGMI), barrier every 32 frames")
+                                      + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")
+                                      + f"; gather_payload={args.gather}, {4 * chan} B/pixel",
+                       "gather_payload": None if world == 1 else args.gather,
+                       "gather_bytes_per_pixel": None if world == 1 else 4 * chan},
             "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
             "fragments_tested_per_frame": int(frags_tested),
             "fragments_written_per_frame": int(frags_written),
@@ -367,6 +384,28 @@ def main():
     dev.close()
     if world > 1 and not args.fake_world:
         dist.destroy_process_group()
+
+
+def launch_ranks_if_needed(args, argv, run=None):
+    """`python bench.py --gpus N` started directly (no WORLD_SIZE in the environment): start the N ranks as FRESH child processes
+    -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>` --
+    forward what they print (rank 0's JSON line) and return their exit code.  This process has not imported torch or touched
+    the GPU and never does (a process that has initialised HIP must not exec or fork workers on this pool); it only waits.
+    Returns None when there is nothing to launch (N = 1, a --fake-world rehearsal, or already a rank of a launched job)."""
+    if args.gpus <= 1 or args.fake_world > 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL / peer-mapped frames across processes need it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = (run or subprocess.run)(cmd, env=env, cwd=ROOT)
+    return int(r.returncode)
 
 
 def kernel_source_hash():

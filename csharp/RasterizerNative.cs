@@ -92,6 +92,8 @@ namespace SoftwareRenderer
     {
         const string Lib = "swr_hip";      // libswr_hip.so
         [DllImport(Lib)] public static extern int swr_abi_version();
+        [DllImport(Lib)] public static extern IntPtr swr_build_info();
+        [DllImport(Lib)] public static extern int swr_numerics_mode(out int fma, out int dotOrder);
         [DllImport(Lib)] public static extern IntPtr swr_last_error(IntPtr ctx);
         [DllImport(Lib)] public static extern int swr_create(int deviceId, out IntPtr ctx);
         [DllImport(Lib)] public static extern void swr_destroy(IntPtr ctx);
@@ -111,6 +113,7 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_flatten_rgb_device(IntPtr ctx, IntPtr deviceRgb);
         [DllImport(Lib)] public static extern int swr_flatten_rgb_device_async(IntPtr ctx, IntPtr deviceRgb);
         [DllImport(Lib)] public static extern int swr_replay_count(IntPtr ctx, out ulong replays);
+        [DllImport(Lib)] public static extern int swr_sync_count(IntPtr ctx, out ulong syncs);
         [DllImport(Lib)] public static extern int swr_host_register(IntPtr ctx, void* ptr, nuint bytes);
         [DllImport(Lib)] public static extern int swr_host_unregister(IntPtr ctx, void* ptr);
         [DllImport(Lib)] public static extern int swr_upload(IntPtr ctx, Vector4* colorRgba, float* depth);
@@ -156,7 +159,7 @@ namespace SoftwareRenderer
                 lock (createLock)
                 {
                     if (ctx != IntPtr.Zero) return ctx;
-                    if (Native.swr_abi_version() != 1) throw new InvalidOperationException("libswr_hip.so: ABI version mismatch");
+                    if (Native.swr_abi_version() != 2) throw new InvalidOperationException("libswr_hip.so: ABI version mismatch");
                     int rc = Native.swr_create(0, out IntPtr c);       // one context drives one GPU; there is NO CPU fallback
                     if (rc != 0) throw new InvalidOperationException($"swr_create failed ({rc}): {Marshal.PtrToStringAnsi(Native.swr_last_error(IntPtr.Zero))}");
                     ctx = c;

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 1
+#define SWR_ABI_VERSION 2     /* 2: swr_bind_framebuffer no longer drains (lifetime rule below); swr_resize / swr_set_band* are no-ops when
+                               * nothing changes; new: swr_sync_count, swr_build_info, swr_numerics_mode */
 
 /* status codes */
 #define SWR_OK                 0
@@ -108,6 +109,15 @@ typedef struct swr_mesh swr_mesh;
 typedef struct swr_texture swr_texture;
 
 int  swr_abi_version(void);
+/* Identity of this build: "hipcc=<compiler version>; csrc_sha256=<hash of the kernel sources>; fma=<0|1>; dot=<0|1|2>".
+ * The lane-to-lane LDS hand-offs of k_cover / k_raster_c are verified per compiler + source pair: the
+ * pair the parity sweeps ran on is committed in profiles/verified_build.json and tests/test_gpu_api.py compares. */
+const char* swr_build_info(void);
+/* The System.Numerics model this library was compiled with (the reference's .NET 9 SIMD paths are not pinned by anything in
+ * its repository): *fma = 1 when Vector4.Transform / Lerp are modelled with fused multiply-adds
+ * (SWR_NUMERICS_FMA), *dot_order = summation order of Vector3.Dot / LengthSquared (SWR_DOT_PAIRWISE: 0 sequential, 1 dpps,
+ * 2 shuffle-adds).  csharp/RasterizerNative.cs probes the running .NET at start-up and loads the library that matches. */
+int  swr_numerics_mode(int* fma, int* dot_order);
 const char* swr_last_error(const swr_context* ctx);   /* ctx may be NULL: last swr_create failure */
 
 /* lifetime -------------------------------------------------------------------------------- */
@@ -127,7 +137,12 @@ int  swr_set_band(swr_context* ctx, int first_tile_row, int n_tile_rows);
 int  swr_set_band_interleaved(swr_context* ctx, int rank, int world, int stripe_tile_rows);
 /* use caller-provided device memory (e.g. a torch tensor that RCCL will gather) for the band's
  * colour (float4 per pixel) and depth (float per pixel); NULL returns to internal storage.  Draws recorded before the
- * call are launched against the buffers bound before it; the call itself does not wait for the GPU. */
+ * call are launched against the buffers bound before it; the call itself does not wait for the GPU.
+ * LIFETIME RULE (ABI 2): a buffer that has been bound stays referenced by the batches flushed against it until the next
+ * VALIDATING call on this context (swr_sync, swr_readback*, swr_get_stats, any pixel accessor, swr_destroy): an optimistic
+ * batch that did not fit its pair buffers is replayed into the buffer it was flushed against at that point.  Keep previously
+ * bound buffers allocated, and do not hand their contents to a consumer as final, until such a call has returned (the caller's
+ * own stream synchronisation is not enough).  swr_replay_count tells whether a replay happened. */
 int  swr_bind_framebuffer(swr_context* ctx, void* color_device_ptr, void* depth_device_ptr);
 int  swr_set_stream(swr_context* ctx, void* hip_stream);      /* hipStream_t; NULL = context's own stream */
 int  swr_clear_color(swr_context* ctx, const float rgba[4]);   /* MainWindow.ClearColorBuffer, MainWindow.cs:400-407 */
@@ -153,6 +168,10 @@ int  swr_flatten_rgb_device(swr_context* ctx, float* d_rgb);
  * (flatten and send them again).  Steady-state frames never replay. */
 int  swr_flatten_rgb_device_async(swr_context* ctx, float* d_rgb);
 int  swr_replay_count(swr_context* ctx, uint64_t* out);
+/* how many times an entry point has made the calling thread wait for the stream so far (hipStreamSynchronize): lets a frame
+ * loop assert that its steady state never blocks (swr_bind_framebuffer, swr_flush, swr_flatten_rgb_device_async, and
+ * swr_resize / swr_set_band* with unchanged arguments do not) */
+int  swr_sync_count(swr_context* ctx, uint64_t* out);
 /* Page-lock a long-lived host buffer (the C# side's pinned ColorBuffer / flatColorBuffer arrays) so that swr_readback /
  * swr_readback_rgb / swr_upload DMA straight into it at PCIe rate instead of going through a pageable staging copy.
  * Optional: unregistered buffers work, only slower.  Unregister before freeing the memory. */

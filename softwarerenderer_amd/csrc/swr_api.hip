@@ -89,6 +89,7 @@ struct swr_context {
     char dev_name[256] = { 0 };
 
     int W = 0, H = 0, tiles_x = 0, tiles_y = 0;
+    bool geometry_applied = false;            // swr_resize has run at least once (a second call with the same size is a no-op)
     bool band_set = false;
     int band_first = 0, band_count = 0;       // as requested by swr_set_band
     int band_ty0 = 0, band_ty1 = 0;           // effective
@@ -125,6 +126,7 @@ struct swr_context {
     swr_stats totals = {};
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
     unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
+    unsigned long long host_syncs = 0;        // times an entry point made the host wait for the stream (swr_sync_count)
 
     int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
     std::vector<EventSpan> spans;
@@ -295,6 +297,7 @@ int validate_locked(swr_context* c);
 int check_list_overflow(swr_context* c);
 
 int sync_locked(swr_context* c) {
+    ++c->host_syncs;
     SWR_HIP(c, hipStreamSynchronize(c->stream));
     int rc = validate_locked(c);
     collect_spans(c);
@@ -461,6 +464,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.fp.near_clip = b.near_clip;
         ra.recs = c->d_recs.as<TriRec>();
         ra.vout = c->d_vout.as<VOut>();
+        ra.vout_bytes = (uint32_t)std::min<size_t>(c->d_vout.cap, 0xfffffff0u);
         ra.draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
         ra.tile_start = c->d_tile_start.as<uint32_t>();
         ra.tile_count = c->d_tile_count.as<uint32_t>();
@@ -517,6 +521,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const size_t nd = b.draws.size();
     std::vector<DrawParams> hp(nd);
     std::vector<BlockMap> vblocks, tblocks;
+    std::vector<uint32_t> frag_reps;
     uint64_t V = 0, T = 0;
     for (size_t i = 0; i < nd; ++i) {
         DrawParams p = b.draws[i].p;
@@ -524,10 +529,21 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         for (uint32_t f = 0; f < p.n_verts; f += 256) vblocks.push_back({ (uint32_t)i, f });
         for (uint32_t f = 0; f < p.n_tris; f += 256) tblocks.push_back({ (uint32_t)i, f });
         V += p.n_verts; T += p.n_tris;
+        // fragment-stage identity: draws that differ only in geometry / matrices / cull mode share one set of fragment constants
+        p.frag_draw = (uint32_t)i;
+        for (uint32_t j : frag_reps) {
+            const DrawParams& q = hp[j];
+            if (q.program == p.program && q.blend == p.blend && q.depth_test == p.depth_test && q.tex == p.tex && q.tex_w == p.tex_w &&
+                q.tex_h == p.tex_h && memcmp(&q.u, &p.u, sizeof p.u) == 0) { p.frag_draw = j; break; }
+        }
+        // a representative must have its k_vertex block 0 run (it writes fog_r1 / fog_den): it has vertices and is not subject to the
+        // device-side frustum test; the list is bounded so that a batch of thousands of distinct materials stays linear
+        if (p.frag_draw == (uint32_t)i && p.n_verts > 0 && !b.draws[i].frustum_cull && frag_reps.size() < 64) frag_reps.push_back((uint32_t)i);
         hp[i] = p;
     }
     const uint64_t spt = b.wireframe ? 6 : 2;        // primitive slots per submitted triangle
-    if (V + 4 * T >= 0xffffffffull || spt * T >= 0xffffffffull)
+    // (V + 4 T vertex records of 64 B: k_raster_c addresses them with 32-bit byte offsets)
+    if (V + 4 * T >= (1ull << 26) || spt * T >= 0xffffffffull)
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
@@ -551,6 +567,13 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 8 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
+        // another tile count (resize / band change): the fragment counters gathered so far move into the carry words of d_total
+        // (swr_get_stats adds them), in stream order, so totals survive a change of geometry
+        if (c->tile_stats_tiles) {
+            hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, c->stream, c->d_tile_stats.as<uint32_t>(),
+                               (uint32_t)c->tile_stats_tiles, c->d_total.as<unsigned long long>() + 4, 1);
+            SWR_HIP(c, hipGetLastError());
+        }
         if ((rc = ensure(c, c->d_tile_stats, (size_t)n_tiles * 12))) return rc;
         SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
         c->tile_stats_tiles = n_tiles;
@@ -755,7 +778,8 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     if (n_tris == 0) return SWR_OK;
     if (band_rejects(c, mesh, model, view, proj)) return SWR_OK;      // nothing of it can land in this band
     // keep a batch within the 32-bit slot / vertex numbering
-    if (c->pend_tris + (uint64_t)n_tris > (1ull << 27) || c->pend_verts + (uint64_t)mesh->n_verts > (1ull << 28)) {
+    // (and the vertex-stage output -- one record per vertex plus four per triangle for the clipper -- below 4 GiB)
+    if (c->pend_verts + (uint64_t)mesh->n_verts + 4 * (c->pend_tris + (uint64_t)n_tris) >= (1ull << 26)) {
         int rc = flush_locked(c);
         if (rc) return rc;
     }
@@ -820,6 +844,25 @@ bool in_band(const swr_context* c, int x, int y) {
 extern "C" {
 
 int swr_abi_version(void) { return SWR_ABI_VERSION; }
+
+// set by csrc/Makefile: the compiler's version line and bench.py --print-src-hash (sha256 over the kernel sources)
+#ifndef SWR_BUILD_HIPCC
+#define SWR_BUILD_HIPCC "unknown"
+#endif
+#ifndef SWR_BUILD_SRC_SHA
+#define SWR_BUILD_SRC_SHA "unknown"
+#endif
+#define SWR_STR2(x) #x
+#define SWR_STR(x) SWR_STR2(x)
+const char* swr_build_info(void) {
+    return "hipcc=" SWR_BUILD_HIPCC "; csrc_sha256=" SWR_BUILD_SRC_SHA "; fma=" SWR_STR(SWR_NUMERICS_FMA) "; dot=" SWR_STR(SWR_DOT_PAIRWISE);
+}
+
+int swr_numerics_mode(int* fma, int* dot_order) {
+    if (!fma || !dot_order) return SWR_ERR_INVALID_ARG;
+    *fma = SWR_NUMERICS_FMA; *dot_order = SWR_DOT_PAIRWISE;
+    return SWR_OK;
+}
 
 const char* swr_last_error(const swr_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -888,36 +931,41 @@ void swr_destroy(swr_context* c) {
 
 int swr_resize(swr_context* c, int width, int height) {
     SWR_ENTER(c);
+    if (width > 65535 || height > 65535) return fail(c, SWR_ERR_INVALID_ARG, "render target larger than 65535");
+    if (c->geometry_applied && width == c->W && height == c->H) return SWR_OK;      // nothing changes: no flush, no wait
     int rc = flush_locked(c);
     if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    if (width > 65535 || height > 65535) return fail(c, SWR_ERR_INVALID_ARG, "render target larger than 65535");
     c->W = width; c->H = height;
-    c->tile_stats_tiles = 0;
+    c->geometry_applied = true;
     return apply_geometry(c);
 }
 
 int swr_set_band(swr_context* c, int first_tile_row, int n_tile_rows) {
     SWR_ENTER(c);
+    {
+        const bool want_band = !(first_tile_row < 0 || n_tile_rows < 0);
+        if (c->il_k == 0 && want_band == c->band_set && (!want_band || (first_tile_row == c->band_first && n_tile_rows == c->band_count)))
+            return SWR_OK;                                                         // the same band again: no flush, no wait
+    }
     int rc = flush_locked(c);
     if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
     c->il_k = 0; c->il_world = 1; c->il_rank = 0;
     if (first_tile_row < 0 || n_tile_rows < 0) { c->band_set = false; }
     else { c->band_set = true; c->band_first = first_tile_row; c->band_count = n_tile_rows; }
-    c->tile_stats_tiles = 0;
     return apply_geometry(c);
 }
 
 int swr_set_band_interleaved(swr_context* c, int rank, int world, int stripe_tile_rows) {
     SWR_ENTER(c);
+    if (world < 1 || rank < 0 || rank >= world || stripe_tile_rows < 1) return fail(c, SWR_ERR_INVALID_ARG, "bad interleaved band arguments");
+    if (c->il_k == stripe_tile_rows && c->il_world == world && c->il_rank == rank) return SWR_OK;     // unchanged: no flush, no wait
     int rc = flush_locked(c);
     if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
-    if (world < 1 || rank < 0 || rank >= world || stripe_tile_rows < 1) return fail(c, SWR_ERR_INVALID_ARG, "bad interleaved band arguments");
     c->band_set = false;
     c->il_k = stripe_tile_rows; c->il_world = world; c->il_rank = rank;
-    c->tile_stats_tiles = 0;
     return apply_geometry(c);
 }
 
@@ -1050,6 +1098,13 @@ int swr_replay_count(swr_context* c, uint64_t* out) {
     SWR_ENTER(c);
     if (!out) return SWR_ERR_INVALID_ARG;
     *out = c->replays;
+    return SWR_OK;
+}
+
+int swr_sync_count(swr_context* c, uint64_t* out) {
+    SWR_ENTER(c);
+    if (!out) return SWR_ERR_INVALID_ARG;
+    *out = c->host_syncs;
     return SWR_OK;
 }
 
@@ -1276,10 +1331,12 @@ int swr_get_stats(swr_context* c, swr_stats* out) {
     if (c->tile_stats_tiles) {
         unsigned long long* d3 = c->d_total.as<unsigned long long>() + 1;
         hipLaunchKernelGGL(k_reduce_tile_stats, dim3(1), dim3(1024), 0, c->stream, c->d_tile_stats.as<uint32_t>(),
-                           (uint32_t)c->tile_stats_tiles, d3);
+                           (uint32_t)c->tile_stats_tiles, d3, 0);
         SWR_HIP(c, hipGetLastError());
         SWR_HIP(c, hipMemcpyAsync(frag, d3, 24, hipMemcpyDeviceToHost, c->stream));
     }
+    unsigned long long carry[3] = { 0, 0, 0 };      // counters of earlier geometries (see the tile_stats_tiles change in the flush)
+    SWR_HIP(c, hipMemcpyAsync(carry, c->d_total.as<unsigned long long>() + 4, 24, hipMemcpyDeviceToHost, c->stream));
     SWR_HIP(c, hipMemcpyAsync(host, c->d_counters.p, sizeof host, hipMemcpyDeviceToHost, c->stream));
     if ((rc = sync_locked(c))) return rc;
     swr_stats s = {};
@@ -1287,7 +1344,7 @@ int swr_get_stats(swr_context* c, swr_stats* out) {
         s.triangles_in += host[i].triangles_in; s.triangles_setup += host[i].triangles_setup;
         s.triangles_clipped += host[i].triangles_clipped; s.tile_pairs += host[i].tile_pairs;
     }
-    s.fragments_tested = frag[0]; s.fragments_shaded = frag[1]; s.fragments_written = frag[2];
+    s.fragments_tested = frag[0] + carry[0]; s.fragments_shaded = frag[1] + carry[1]; s.fragments_written = frag[2] + carry[2];
     s.tile_pairs += c->host_tile_pairs;
     s.flushes = c->totals.flushes;
     *out = s;
@@ -1299,6 +1356,7 @@ int swr_reset_stats(swr_context* c) {
     int rc = flush_locked(c); if (rc) return rc;
     SWR_HIP(c, hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream));
     if (c->tile_stats_tiles) SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, c->tile_stats_tiles * 12, c->stream));
+    SWR_HIP(c, hipMemsetAsync(c->d_total.as<unsigned long long>() + 4, 0, 24, c->stream));
     c->totals = {}; c->host_tile_pairs = 0;
     return sync_locked(c);
 }

@@ -74,6 +74,11 @@ struct DrawParams {
                             // written on the device by k_vertex (the fragment program's fog division, Renderer.cs:855)
     float tex_wf, tex_hf;   // (float)tex_w, (float)|tex_h|: Texture.Sample's `u * Width` / `v * Height` operands (Texture.cs:50-51)
     float fog_den;          // u.fog_end - u.fog_start, written next to fog_r1 by k_vertex: one float subtraction per draw, not per fragment
+    uint32_t frag_draw;     // index of the FIRST draw of the batch whose fragment-stage state (program, blend, depth test, texture,
+                            // uniforms) equals this draw's (execute_batch): k_setup writes it into TriRec::draw_flags instead of the
+                            // draw's own index, so k_raster_c -- which cuts a fragment chunk where the draw changes, because the
+                            // per-draw constants are wave-uniform -- sees the 16 meshes of one model with one material as ONE draw
+    uint32_t pad_;
 };
 static_assert(offsetof(DrawParams, fog_den) == offsetof(DrawParams, fog_r1) + 12, "k_vertex writes fog_den three floats after fog_r1");
 

@@ -172,6 +172,11 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 // One thread per submitted triangle.  Filled mode: slot 2*t is the triangle itself (or the first fan triangle of
 // its clipped polygon), slot 2*t+1 the second fan triangle.  Wireframe: six slots per triangle, three DrawLine
 // edges per fan triangle, in the reference's call order.  Slots keep submission order, which the per-tile lists preserve.
+#ifdef SWR_NO_FRAG_ALIAS            // tools/ablate.py A/B: every draw keeps its own index (a chunk is cut at every mesh boundary)
+#define SWR_FRAG_DRAW(dp, bm) ((bm).draw)
+#else
+#define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
+#endif
 __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
@@ -252,13 +257,13 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                     const uint32_t pbase = clip_pool_base + 4u * gt;
                     for (int k = 0; k < n; ++k) store_vout(pool + k, poly[k].v);
                     // fan (0, k, k+1), Rasterizer.cs:154-157
-                    n_setup += setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[1], poly[2],
+                    n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), poly[0], poly[1], poly[2],
                                               pbase, pbase + 1, pbase + 2, recs + slot, &tbs[0], wireframe != 0);
-                    if (n == 4) n_setup += setup_triangle(fp, dp->cull, bm.draw, poly[0], poly[2], poly[3],
+                    if (n == 4) n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), poly[0], poly[2], poly[3],
                                                           pbase, pbase + 2, pbase + 3, recs + slot + per_fan, &tbs[3], wireframe != 0);
                 }
             } else {
-                n_setup += setup_triangle(fp, dp->cull, bm.draw, v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], wireframe != 0);
+                n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], wireframe != 0);
             }
         }
         if (wireframe) {

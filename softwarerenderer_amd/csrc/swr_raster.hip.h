@@ -17,6 +17,7 @@ struct RasterArgs {
     const DrawParams* __restrict__ draws;
     const uint32_t* __restrict__ tile_start;
     const uint32_t* __restrict__ tile_count;
+    uint32_t vout_bytes;                       // size of the VOut array (< 4 GiB: k_raster_c addresses it with 32-bit byte offsets)
     const uint4* __restrict__ pair_refs;       // per pair {slot, vertex refs of outputs[0..2]} (k_cover)
     const uint32_t* __restrict__ tile_order;   // band-local tile indices, heaviest first (k_tile_place)
     uint32_t n_tiles;
@@ -146,11 +147,12 @@ __device__ __forceinline__ float4 fs_phong4(const DrawParams* __restrict__ dp, c
 // The varyings of one triangle's three outputs, as the fragment path reads them (VOut as four float4:
 // [0] clip  [1] color  [2] uv.xy, wn.xy  [3] wn.z, wpos.xyz).  k_raster_c stages them per pair in LDS.
 struct TriVaryings {
-    float4 a_clip, b_clip, c_clip;
+    float a_cz, b_cz, c_cz;                    // clip.z of each output (the fog depth; clip.xy are never read, clip.w is a_w ...)
     float4 a_col, b_col, c_col;
     float4 a_uvn, b_uvn, c_uvn;
     float a_wnz, b_wnz, c_wnz;
     float a_r1, b_r1, c_r1;                    // rcp_refined(clip.w) of each output (staged once per pair)
+    float a_w, b_w, c_w;                       // clip.w of each output (= a_clip.w ...; staged, so that the divisions do not wait for the rows)
     bool fastdiv;                              // the three clip.w are in div_operand_safe()'s range
     float a_wpos[3], b_wpos[3], c_wpos[3];     // PHONG only
 };
@@ -162,16 +164,15 @@ template <bool PHONG = true>
 __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ dp, const DrawConsts& dc, int program, bool interp,
                                                  const TriVaryings& V, float w0f, float w1f, float w2f) {
     const bool simple = program == SWR_PROG_FLAT_COLOR || program == SWR_PROG_GOURAUD;
-    const float4 a_clip = V.a_clip, b_clip = V.b_clip, c_clip = V.c_clip;
     const float4 a_col = V.a_col, b_col = V.b_col, c_col = V.c_col;
     const float4 a_uvn = V.a_uvn, b_uvn = V.b_uvn, c_uvn = V.c_uvn;
     if (simple && !interp) return a_col;                                                             // :622-627
 
     // :576-578, true divisions: the denominators are per pair, so their refined reciprocals are staged and each quotient
     // is the division's own mul + 4 fma core (div_core, swr_device.h); operands outside its range take the full sequence
-    float ra = div_core(w0f, a_clip.w, V.a_r1);
-    float rb = div_core(w1f, b_clip.w, V.b_r1);
-    float rc = div_core(w2f, c_clip.w, V.c_r1);
+    float ra = div_core(w0f, V.a_w, V.a_r1);
+    float rb = div_core(w1f, V.b_w, V.b_r1);
+    float rc = div_core(w2f, V.c_w, V.c_r1);
     const bool fast = V.fastdiv && div_operands_safe3_arith(w0f, w1f, w2f);
     float inv_sum = (ra + rb) + rc;         // :579
     // :582.  On the fast path |ra|, |rb|, |rc| <= 2^40 / 2^-40, so |inv_sum| < 2^82: inside recip_core's range unless it
@@ -181,9 +182,9 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         // one cold block for everything outside the cores' ranges (a single division on its own would be if-converted
         // into a select, i.e. computed by every fragment)
         if (!fast) {
-            ra = w0f / a_clip.w;
-            rb = w1f / b_clip.w;
-            rc = w2f / c_clip.w;
+            ra = w0f / V.a_w;
+            rb = w1f / V.b_w;
+            rc = w2f / V.c_w;
         }
         inv_sum = (ra + rb) + rc;
         w = 1.0f / inv_sum;
@@ -203,7 +204,11 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     if (dc.tex && dc.tex_h > 0) {
         // global (not generic) address space + 32-bit index: one global_load with the draw's texture pointer as scalar base
         typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+#ifdef SWR_ABL_TEXFIXED      // tools/ablate.py latency probe: same instructions, every lane fetches one of 64 neighbouring texels (always cache hits)
+        f.texel = ((global_u32_ptr)(uintptr_t)dc.tex)[texture_nearest_index(dc.tex_w, dc.tex_h, dc.tex_wf, dc.tex_hf, f.u, f.v) & 63u];
+#else
         f.texel = ((global_u32_ptr)(uintptr_t)dc.tex)[texture_nearest_index(dc.tex_w, dc.tex_h, dc.tex_wf, dc.tex_hf, f.u, f.v)];
+#endif
         f.texel_loaded = true;
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
@@ -214,7 +219,7 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     } else {
         f.color = a_col;
     }
-    f.clip_z = SWR_PERSP(a_clip.z, b_clip.z, c_clip.z);
+    f.clip_z = SWR_PERSP(V.a_cz, V.b_cz, V.c_cz);
 #undef SWR_PERSP
     if (interp) {
         float wa = ra * w, wb = rb * w, wc = rc * w;      // :583-585
@@ -269,9 +274,9 @@ __global__ __launch_bounds__(256) void k_texture_sample(const uint8_t* __restric
     if (i < n) out[i] = texture_sample(tex, w, h, uv[i].x, uv[i].y);
 }
 
-// sums the per-tile fragment counters; one block
+// sums the per-tile fragment counters; one block (accumulate: adds to out3 instead of overwriting it)
 __global__ __launch_bounds__(1024) void k_reduce_tile_stats(const uint32_t* __restrict__ ts, uint32_t n_tiles,
-                                                            unsigned long long* __restrict__ out3) {
+                                                            unsigned long long* __restrict__ out3, int accumulate) {
     __shared__ unsigned long long s[3][16];
     unsigned long long t[3] = { 0, 0, 0 };
     for (uint32_t i = threadIdx.x; i < n_tiles; i += 1024u) { t[0] += ts[3 * i]; t[1] += ts[3 * i + 1]; t[2] += ts[3 * i + 2]; }
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(1024) void k_reduce_tile_stats(const uint32_t* __re
     if (threadIdx.x < 3) {
         unsigned long long sum = 0;
         for (int wv = 0; wv < 16; ++wv) sum += s[threadIdx.x][wv];
-        out3[threadIdx.x] = sum;
+        out3[threadIdx.x] = accumulate ? out3[threadIdx.x] + sum : sum;
     }
 }
 

@@ -22,6 +22,7 @@
 //   not cover, so the links that can run early do: the next window's head words are read at the cut, each lane's next pair and
 //   that pair's prefix counts between replay and shading, the row-start table and stored depth ahead of the election's atomic.
 #pragma once
+#include <type_traits>
 #include "swr_device.h"
 #include "swr_raster.hip.h"
 
@@ -319,9 +320,6 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_BATCH
 #define SWR_BATCH 16
 #endif
-#ifndef SWR_RASTER_MINWAVES
-#define SWR_RASTER_MINWAVES 4
-#endif
 #ifndef SWR_BATCH_FRAGS
 #define SWR_BATCH_FRAGS 2048                   // fragments per batch (a pair covers <= 256 pixels, so at least 8 pairs always fit)
 #endif
@@ -336,29 +334,73 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_WINDOW_PHONG
 #define SWR_WINDOW_PHONG 24
 #endif
+// Where the three outputs' varyings of a pair come from when a fragment is shaded (SWR_VARY_GLOBAL; VG in the code):
+//   staged in LDS (round 2's layout): nine rows per pair (twelve with the 4-light program's world position), 292 B per pair;
+//   from the vertex-stage output in HBM: buffer loads with staged byte offsets -- the lanes of one pair read the same 16-byte rows,
+//     a chunk touches the vertices of 3-4 pairs -- and only what the chain replay, the depth test and Interpolate's divisions need
+//     stays staged: 160 B per pair, 8,080 B per wave with 16 pairs = 18 waves per CU instead of 16 (LDS is allocated in units of
+//     1,280 B, tools/ubench/lds_occupancy.hip).
+// Measured on cfg3 (profiles/r03_raster_experiments.md): the loads cost 7 % at equal occupancy and the two extra waves return 4-5 %,
+// so the kernels WITHOUT the 4-light program keep the staged layout; the kernels that carry it (PHONG = true: they had to shrink
+// their batch to 12 pairs to stay at 16 waves) take the loads: 16 pairs per batch again and 18 waves, cfg4 -5 %.
+//   0 = always staged, 1 = always from HBM, 2 (default) = from HBM in the PHONG kernels only
+#ifndef SWR_VARY_GLOBAL
+#define SWR_VARY_GLOBAL 2
+#endif
+#ifndef SWR_RASTER_MINWAVES
+#define SWR_RASTER_MINWAVES 4
+#endif
+// when the rows are requested (VG): 0 = by the fragments that passed the depth test, 1 = by every fragment of the chunk as soon as
+// its pair is known (ahead of the election), 2 = by the fragments that survive the chunk's cut (ahead of the chain replay; spills),
+// 3 = as 2 but only the uv rows, the texel address hangs on them (cfg3: 0.4333 / 0.4303 / 0.4241 / 0.4290 ms for 0 / 1 / 2 / 3)
+#ifndef SWR_VARY_EARLY
+#define SWR_VARY_EARLY 3
+#endif
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
 //   3: row steps b12,b20,b01, stream position of the pair's first fragment (int bits)
-//   4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the output's wn.z, y by the refined reciprocal of clip.w),
+//   SWR_VARY_GLOBAL: 4: byte offsets of outputs[0..2] in the VOut array, clip.w of outputs[0]
+//                    5: refined reciprocals of the three clip.w (Interpolate's divisions, see div_core), clip.w of outputs[1]
+//                    (clip.w of outputs[2] rides in the row-start entry)
+//   else 4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the output's wn.z, y by the refined reciprocal of clip.w),
 //   color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
-// LDS per wave is the occupancy limit (4 waves per SIMD = 10,240 B): 10,192 B used.
+#ifdef SWR_ABL_VARY_ALIAS
+#define SWR_VROW(r, idx) L.stagev[((r) >= 4 ? (r) - 4 : 0)][(idx) % WaveLdsC<PHONG>::VB]
+#else
+#define SWR_VROW(r, idx) L.stage[r][idx]
+#endif
 template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
-    static constexpr int NQ = PHONG ? 16 : 13;
-    static constexpr int BATCH = PHONG ? SWR_BATCH_PHONG : SWR_BATCH;       // pairs staged per batch
-    static constexpr int WINDOW = PHONG ? SWR_WINDOW_PHONG : SWR_WINDOW;    // candidate pairs examined per batch
+    static constexpr bool VG = SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG);
+    static constexpr int NQ = VG ? 6 : (PHONG ? 16 : 13);
+    static constexpr int BATCH = (PHONG && !VG) ? SWR_BATCH_PHONG : SWR_BATCH;       // pairs staged per batch
+    static constexpr int WINDOW = (PHONG && !VG) ? SWR_WINDOW_PHONG : SWR_WINDOW;    // candidate pairs examined per batch
+    static constexpr int RT_ROWS = VG ? 8 : 4;     // a row-start entry every RT_ROWS rows of a pair
+    static constexpr int RT_N = 16 / RT_ROWS - 1;  // entries per pair (rows RT_ROWS, 2 RT_ROWS, ...)
     float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
     float z[256];
+#ifdef SWR_ABL_VARY_ALIAS            // tools/ablate.py occupancy probe: the varying rows of only this many pairs exist (pair t uses t % n: wrong
+    static constexpr int VB = SWR_ABL_VARY_ALIAS;     // colours, identical work): the layout shrinks without changing the instruction stream
+    float4 stage[4][BATCH];
+    float4 stagev[NQ - 4][VB];
+#else
     float4 stage[NQ][BATCH];         // batch (non-empty pairs only, compacted): per-pair fragment inputs
+#endif
     uint32_t mask[BATCH][8];         // coverage masks
     uint32_t wpre[BATCH][4];         // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
     uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (first - 1) set for every pair t >= 1 (first = its stream position): pair of fragment g = #bits below g
     uint32_t touched[32];            // chunk duplicate election: pixel p claimed <=> bit (p >> 5) of word (p & 31) -- neighbouring
                                      // pixels (the usual content of a chunk) fall into different words: no same-address atomics
-    float rowtab[3][3][BATCH];       // [q][edge][pair]: the pair's edge values at the start of its rows 4, 8, 12 (q = 0, 1, 2), i.e.
-                                     // the reference's row chain (Rasterizer.cs:532-534) run once per pair at staging: a fragment's
-                                     // row replay is then at most 3 add steps from the nearest entry instead of up to 15
+#ifdef SWR_ABL_LDSBYTES             // tools/ablate.py occupancy probe: dead LDS that lowers the waves per SIMD, nothing else changes
+    uint32_t abl_pad[SWR_ABL_LDSBYTES / 4];
+#endif
+    struct RowStart3 { float x, y, z; };
+    typedef typename std::conditional<VG, float4, RowStart3>::type RowStart;     // (the staged-varyings layout has no room for a fourth word)
+    RowStart rowtab[RT_N][BATCH];    // [q][pair]: the pair's edge values at the start of its rows RT_ROWS (q + 1), i.e. the reference's
+                                     // row chain (Rasterizer.cs:532-534) run once per pair at staging: a fragment's row replay is then
+                                     // at most RT_ROWS - 1 add steps from the nearest entry instead of up to 15
+                                     // (.w: unused; with SWR_VARY_GLOBAL entry 0 carries clip.w of outputs[2])
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -378,10 +420,13 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
 // the switches fold away); -1 = read them from the draw at run time.
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
-static_assert(SWR_BATCH != 16 || SWR_BATCH_FRAGS != 2048 || sizeof(WaveLdsC<false>) <= 10240, "4 waves per SIMD need <= 10,240 B of LDS per wave");
-static_assert(SWR_BATCH_PHONG != 12 || SWR_BATCH_FRAGS != 2048 || sizeof(WaveLdsC<true>) <= 10240, "4 waves per SIMD need <= 10,240 B of LDS per wave");
+#if !defined(SWR_ABL_LDSBYTES) && !defined(SWR_ABL_VARY_ALIAS)
+// LDS is allocated in units of 1,280 B (tools/ubench/lds_occupancy.hip: 16 one-wave workgroups per CU up to 10,240 B, 18 up to 8,960 B,
+// 21 up to 7,680 B, 25 up to 6,400 B, 32 up to 5,120 B)
+static_assert(sizeof(WaveLdsC<false>) <= 10240 && sizeof(WaveLdsC<true>) <= 10240, "16 waves per CU need <= 10,240 B of LDS per wave");
+#endif
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
-__global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+__global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG)) ? 5 : SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
     if (a.ctrl->poison) return;
@@ -407,16 +452,53 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
     const uint32_t start = a.tile_start[tile];
     WaveLdsC<PHONG>& L = s_w;
-    auto load_varyings = [&L](int t, bool fastdiv) {
-        TriVaryings V;
-        V.a_clip = L.stage[4][t]; V.a_col = L.stage[5][t]; V.a_uvn = L.stage[6][t];
-        V.b_clip = L.stage[7][t]; V.b_col = L.stage[8][t]; V.b_uvn = L.stage[9][t];
-        V.c_clip = L.stage[10][t]; V.c_col = L.stage[11][t]; V.c_uvn = L.stage[12][t];
-        V.a_wnz = V.a_clip.x; V.b_wnz = V.b_clip.x; V.c_wnz = V.c_clip.x;
-        V.a_r1 = V.a_clip.y; V.b_r1 = V.b_clip.y; V.c_r1 = V.c_clip.y;
+    constexpr bool VG = WaveLdsC<PHONG>::VG;
+    constexpr int RT_ROWS = WaveLdsC<PHONG>::RT_ROWS;
+    // the VOut array as a raw buffer: one 32-bit byte offset per vertex in a VGPR, the 16-byte row as the instruction's immediate
+    const __amdgpu_buffer_rsrc_t vout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.vout, 0, (int)a.vout_bytes, 0x00020000);
+    // part: 0 = everything, 1 = only the three uv rows (SWR_VARY_EARLY 3: requested ahead of the chain replay, the texel address hangs
+    // on them), 2 = everything but the uv rows, which `V` already holds
+    auto load_varyings = [&L, vout_rsrc](int t, bool fastdiv, int part = 0, TriVaryings V = TriVaryings()) {
+        if (VG) {
+            const float4 q4 = L.stage[VG ? 4 : 0][t], q5 = L.stage[VG ? 5 : 0][t];
+            const uint32_t oa = __float_as_uint(q4.x), ob = __float_as_uint(q4.y), oc = __float_as_uint(q4.z);
+            auto row = [&](uint32_t off, int r) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(vout_rsrc, (int)off + 16 * r, 0, 0);
+                return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+            };
+            auto word = [&](uint32_t off, int byte) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(vout_rsrc, (int)off + byte, 0, 0)); };
+            // in the order Interpolate consumes them: uv (the texel address), clip.z, colour, the normal's z
+            if (part != 2) { V.a_uvn = row(oa, 2); V.b_uvn = row(ob, 2); V.c_uvn = row(oc, 2); }
+            if (part == 1) return V;
+            V.a_cz = word(oa, 8); V.b_cz = word(ob, 8); V.c_cz = word(oc, 8);
+            V.a_col = row(oa, 1); V.b_col = row(ob, 1); V.c_col = row(oc, 1);
+            if (PHONG) {
+                const float4 a3 = row(oa, 3), b3 = row(ob, 3), c3 = row(oc, 3);
+                V.a_wnz = a3.x; V.b_wnz = b3.x; V.c_wnz = c3.x;
+                V.a_wpos[0] = a3.y; V.a_wpos[1] = a3.z; V.a_wpos[2] = a3.w;
+                V.b_wpos[0] = b3.y; V.b_wpos[1] = b3.z; V.b_wpos[2] = b3.w;
+                V.c_wpos[0] = c3.y; V.c_wpos[1] = c3.z; V.c_wpos[2] = c3.w;
+            } else {
+                V.a_wnz = word(oa, 48); V.b_wnz = word(ob, 48); V.c_wnz = word(oc, 48);
+            }
+            // the divisions' operands come from LDS (staged once per pair): they do not wait for the rows above
+            V.a_r1 = q5.x; V.b_r1 = q5.y; V.c_r1 = q5.z;
+            V.a_w = q4.w; V.b_w = q5.w;
+            if constexpr (VG) V.c_w = L.rowtab[0][t].w;
+            V.fastdiv = fastdiv;
+            return V;
+        }
+        const float4 a_clip = SWR_VROW(VG ? 0 : 4, t), b_clip = SWR_VROW(VG ? 0 : 7, t), c_clip = SWR_VROW(VG ? 0 : 10, t);
+        V.a_col = SWR_VROW(VG ? 0 : 5, t); V.a_uvn = SWR_VROW(VG ? 0 : 6, t);
+        V.b_col = SWR_VROW(VG ? 0 : 8, t); V.b_uvn = SWR_VROW(VG ? 0 : 9, t);
+        V.c_col = SWR_VROW(VG ? 0 : 11, t); V.c_uvn = SWR_VROW(VG ? 0 : 12, t);
+        V.a_wnz = a_clip.x; V.b_wnz = b_clip.x; V.c_wnz = c_clip.x;
+        V.a_r1 = a_clip.y; V.b_r1 = b_clip.y; V.c_r1 = c_clip.y;
+        V.a_cz = a_clip.z; V.b_cz = b_clip.z; V.c_cz = c_clip.z;
+        V.a_w = a_clip.w; V.b_w = b_clip.w; V.c_w = c_clip.w;
         V.fastdiv = fastdiv;
         if (PHONG) {
-            const float4 a3 = L.stage[PHONG ? 13 : 0][t], b3 = L.stage[PHONG ? 14 : 0][t], c3 = L.stage[PHONG ? 15 : 0][t];
+            const float4 a3 = SWR_VROW((PHONG && !VG) ? 13 : 0, t), b3 = SWR_VROW((PHONG && !VG) ? 14 : 0, t), c3 = SWR_VROW((PHONG && !VG) ? 15 : 0, t);
             V.a_wpos[0] = a3.y; V.a_wpos[1] = a3.z; V.a_wpos[2] = a3.w;
             V.b_wpos[0] = b3.y; V.b_wpos[1] = b3.z; V.b_wpos[2] = b3.w;
             V.c_wpos[0] = c3.y; V.c_wpos[1] = c3.z; V.c_wpos[2] = c3.w;
@@ -544,19 +626,30 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const uint4 m0 = masks[2 * (size_t)pidx], m1 = masks[2 * (size_t)pidx + 1];
             const float4* __restrict__ fq = reinterpret_cast<const float4*>(a.recs + ref.x);
             const float4 f0 = fq[0], f1 = fq[1], f2 = fq[2], f3 = fq[3];
-            const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
-            const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + ref.z);
-            const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + ref.w);
-            const float4 a3 = pa[3], b3 = pb[3], c3 = pc[3];
-            float4 a0 = pa[0], b0 = pb[0], c0 = pc[0];
-            a0.x = a3.x; b0.x = b3.x; c0.x = c3.x;                           // clip.x is not read by fragments: wn.z rides there
-            // ... nor is clip.y: the refined reciprocal of clip.w rides there (Interpolate's divisions, see div_core)
-            const bool fastdiv = div_operands_safe3(a0.w, b0.w, c0.w);
-            a0.y = rcp_refined(a0.w); b0.y = rcp_refined(b0.w); c0.y = rcp_refined(c0.w);
-            L.stage[4][ci] = a0; L.stage[5][ci] = pa[1]; L.stage[6][ci] = pa[2];
-            L.stage[7][ci] = b0; L.stage[8][ci] = pb[1]; L.stage[9][ci] = pb[2];
-            L.stage[10][ci] = c0; L.stage[11][ci] = pc[1]; L.stage[12][ci] = pc[2];
-            if (PHONG) { L.stage[PHONG ? 13 : 0][ci] = a3; L.stage[PHONG ? 14 : 0][ci] = b3; L.stage[PHONG ? 15 : 0][ci] = c3; }
+            bool fastdiv;
+            float wc_stage = 0.0f;                                               // VG: clip.w of outputs[2] (rides in the row-start entry)
+            if (VG) {
+                // only the three clip.w: the varyings themselves are fetched per fragment (load_varyings)
+                const float wa = a.vout[ref.y].clip[3], wb = a.vout[ref.z].clip[3], wc = a.vout[ref.w].clip[3];
+                fastdiv = div_operands_safe3(wa, wb, wc);
+                L.stage[VG ? 4 : 0][ci] = make_float4(__uint_as_float(ref.y << 6), __uint_as_float(ref.z << 6), __uint_as_float(ref.w << 6), wa);
+                L.stage[VG ? 5 : 0][ci] = make_float4(rcp_refined(wa), rcp_refined(wb), rcp_refined(wc), wb);
+                wc_stage = wc;
+            } else {
+                const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
+                const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.vout + ref.z);
+                const float4* __restrict__ pc = reinterpret_cast<const float4*>(a.vout + ref.w);
+                const float4 a3 = pa[3], b3 = pb[3], c3 = pc[3];
+                float4 a0 = pa[0], b0 = pb[0], c0 = pc[0];
+                a0.x = a3.x; b0.x = b3.x; c0.x = c3.x;                           // clip.x is not read by fragments: wn.z rides there
+                // ... nor is clip.y: the refined reciprocal of clip.w rides there (Interpolate's divisions, see div_core)
+                fastdiv = div_operands_safe3(a0.w, b0.w, c0.w);
+                a0.y = rcp_refined(a0.w); b0.y = rcp_refined(b0.w); c0.y = rcp_refined(c0.w);
+                SWR_VROW(VG ? 0 : 4, ci) = a0; SWR_VROW(VG ? 0 : 5, ci) = pa[1]; SWR_VROW(VG ? 0 : 6, ci) = pa[2];
+                SWR_VROW(VG ? 0 : 7, ci) = b0; SWR_VROW(VG ? 0 : 8, ci) = pb[1]; SWR_VROW(VG ? 0 : 9, ci) = pb[2];
+                SWR_VROW(VG ? 0 : 10, ci) = c0; SWR_VROW(VG ? 0 : 11, ci) = pc[1]; SWR_VROW(VG ? 0 : 12, ci) = pc[2];
+                if (PHONG) { SWR_VROW((PHONG && !VG) ? 13 : 0, ci) = a3; SWR_VROW((PHONG && !VG) ? 14 : 0, ci) = b3; SWR_VROW((PHONG && !VG) ? 15 : 0, ci) = c3; }
+            }
             {
                 const float t0x = f0.x, t1x = f0.y, t2x = f0.z, t0y = f0.w, t1y = f1.x, t2y = f1.y;
                 const uint32_t fbx = __float_as_uint(f3.y), fby = __float_as_uint(f3.z);
@@ -582,13 +675,16 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 L.stage[2][ci] = make_float4(a12, a20, a01, __uint_as_float(fs));
                 L.stage[3][ci] = make_float4(b12, b20, b01, __uint_as_float(pre));
                 if (ci > 0) atomicOr(&L.head[(pre - 1u) >> 5], 1u << ((pre - 1u) & 31u));
-                // the reference's row chain from the pair's first row, 12 steps: the values at rows 4, 8 and 12 are kept
+                // the reference's row chain from the pair's first row: the values at rows RT_ROWS, 2 RT_ROWS, ... are kept
                 float rw0 = r0.x, rw1 = r0.y, rw2 = r0.z;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
+                for (int q = 0; q < WaveLdsC<PHONG>::RT_N; ++q) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { rw0 += b12; rw1 += b20; rw2 += b01; }                  // :532-534
-                    L.rowtab[q][0][ci] = rw0; L.rowtab[q][1][ci] = rw1; L.rowtab[q][2][ci] = rw2;
+                    for (int i = 0; i < RT_ROWS; ++i) { rw0 += b12; rw1 += b20; rw2 += b01; }            // :532-534
+                    typename WaveLdsC<PHONG>::RowStart e;
+                    e.x = rw0; e.y = rw1; e.z = rw2;
+                    if constexpr (VG) e.w = wc_stage;
+                    L.rowtab[q][ci] = e;
                 }
             }
             *reinterpret_cast<uint4*>(&L.mask[ci][0]) = m0;
@@ -644,6 +740,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
 #endif
             const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
+            TriVaryings Vg = TriVaryings();
+            if (VG && SWR_VARY_EARLY == 1) { if (valid) Vg = load_varyings(t, (__float_as_uint(f1.w) & SWR_FLAG_FASTDIV) != 0u); }
 #ifndef SWR_NO_HEAD_PREFETCH
             int k = valid ? g - (int)pre_n : 0;
 #else
@@ -691,11 +789,12 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
             // left it and no two lanes that survive the cut share a pixel, so reading before the cut changes nothing.
             const uint32_t fs_early = __float_as_uint(f2.w);
             const int nrow_e = (pix >> 4) - (int)(fs_early >> 8);          // (lines, invalid lanes: any value; q stays in 0..3)
-            const int q_e = nrow_e >> 2, qi_e = max(q_e, 1) - 1;
+            const int q_e = nrow_e / RT_ROWS, qi_e = max(q_e, 1) - 1;
             // (not in the row-early-out kernels: they are at the register limit, and three spilled dwords cost more than the round trip)
             float t0r_e = 0.0f, t1r_e = 0.0f, t2r_e = 0.0f, z_old = 0.0f;
             if (!EARLYOUT) {
-                t0r_e = L.rowtab[qi_e][0][t]; t1r_e = L.rowtab[qi_e][1][t]; t2r_e = L.rowtab[qi_e][2][t];
+                const auto rt = L.rowtab[qi_e][t];
+                t0r_e = rt.x; t1r_e = rt.y; t2r_e = rt.z;
                 z_old = L.z[pix];
             }
             // duplicate election: of the lanes that share a pixel in this chunk all but one must wait.  Which of them
@@ -733,6 +832,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                 t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
             }
             const bool act = lane < cut;
+            if (VG && SWR_VARY_EARLY == 2) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u); }
+            if (VG && SWR_VARY_EARLY == 3) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 1); }
 #ifndef SWR_NO_HEAD_PREFETCH
             {   // (the head array has two spare words behind the last position: reading past the batch's end is in bounds)
                 const int hw_next = (pos + cut) >> 5;
@@ -788,10 +889,10 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
 #endif
                     // rows: from the nearest staged row start (rowtab: rows 4, 8, 12 of the pair), at most 3 steps
                     {
-                        const int q = nrow >> 2;
-                        if (EARLYOUT) { t0r_e = L.rowtab[qi_e][0][t]; t1r_e = L.rowtab[qi_e][1][t]; t2r_e = L.rowtab[qi_e][2][t]; }
+                        const int q = nrow / RT_ROWS;
+                        if (EARLYOUT) { const auto rt = L.rowtab[qi_e][t]; t0r_e = rt.x; t1r_e = rt.y; t2r_e = rt.z; }
                         if (q > 0) { w0 = t0r_e; w1 = t1r_e; w2 = t2r_e; }          // (read ahead of the election, see there)
-                        const int rem = nrow & 3;
+                        const int rem = nrow & (RT_ROWS - 1);
                         for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
                     }
                     for (int i = 0; i < ncol; ++i) { w0 += f2.x; w1 += f2.y; w2 += f2.z; }                // :527-529
@@ -811,7 +912,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
                         const float4 src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
-                                                                 load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
+                                                                 (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
+                                                                 (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
                         if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
@@ -825,7 +927,8 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
                         e_src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
-                                                      load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
+                                                      (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
+                                                      (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }
                 }
@@ -882,9 +985,13 @@ __global__ __launch_bounds__(64, SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs
     }
 
     // ---- write back: each wave store covers 4 rows x 256 B (colour) / 4 rows x 64 B (Z) ----
+    // (the addresses are derived from a lane id the optimiser cannot connect with the one of the tile init: otherwise it keeps the
+    //  init's four 64-bit pixel offsets, LDS addresses and bounds masks -- 25 VGPRs -- alive across the whole batch loop)
+    int lane_wb = lane;
+    asm volatile("" : "+v"(lane_wb));
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
-        const int p = rr * 64 + lane;
+        const int p = rr * 64 + lane_wb;
         const int gx = x0 + (p & 15), gy = y0 + (p >> 4);
         if (gx < W && gy < H) {
             const size_t gi = (size_t)(ty_local * SWR_TILE + (p >> 4)) * (size_t)W + (size_t)gx;     // the band's buffers hold its tile rows consecutively

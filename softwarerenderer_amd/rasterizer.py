@@ -167,6 +167,22 @@ class Device:
         self._ck(self._lib.swr_replay_count(self._ctx, C.byref(out)))
         return int(out.value)
 
+    def sync_count(self) -> int:
+        """Times an entry point has made the host wait for the stream (swr_sync_count): a steady-state frame loop adds none."""
+        out = C.c_uint64(0)
+        self._ck(self._lib.swr_sync_count(self._ctx, C.byref(out)))
+        return int(out.value)
+
+    def build_info(self) -> str:
+        """`hipcc=...; csrc_sha256=...; fma=..; dot=..` of the loaded library (swr_build_info)."""
+        return self._lib.swr_build_info().decode()
+
+    def numerics_mode(self):
+        """(fma, dot_order) the loaded library was compiled with (SWR_NUMERICS_FMA, SWR_DOT_PAIRWISE)."""
+        f, d = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.swr_numerics_mode(C.byref(f), C.byref(d)))
+        return int(f.value), int(d.value)
+
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.swr_set_stream(self._ctx, C.c_void_p(hip_stream)))
 
@@ -262,36 +278,57 @@ class MainWindow:
 
     def _activate(self):
         """A context owns ONE framebuffer (one MainWindow in the reference).  Several MainWindow objects on one Device
-        take turns: the one being used re-applies its geometry first; its previous pixels are then undefined."""
+        take turns: the one being used re-applies its geometry first; its previous pixels are then undefined.  The window that
+        is already active issues only the call for what changed (BindFramebuffer -> swr_bind_framebuffer alone: no flush-and-wait,
+        fragment counters keep accumulating); the C side also ignores a resize / band that changes nothing."""
         if getattr(self._dev, "_active_window", None) is self:
             return
+        self._apply_size()
+        self._apply_band()
+        self._apply_binding()
+        self._dev._active_window = self
+
+    def _apply_size(self):
+        self._dev._ck(self._dev._lib.swr_resize(self._dev._ctx, self.RenderWidth, self.RenderHeight))
+
+    def _apply_band(self):
         lib, ctx = self._dev._lib, self._dev._ctx
-        self._dev._ck(lib.swr_resize(ctx, self.RenderWidth, self.RenderHeight))
         if self._band is not None and len(self._band) == 3:
             self._dev._ck(lib.swr_set_band_interleaved(ctx, *self._band))
         else:
             b = self._band if self._band is not None else (-1, -1)
             self._dev._ck(lib.swr_set_band(ctx, b[0], b[1]))
+
+    def _apply_binding(self):
         cb = self._bound if self._bound is not None else (None, None)
-        self._dev._ck(lib.swr_bind_framebuffer(ctx, C.c_void_p(cb[0]) if cb[0] else None, C.c_void_p(cb[1]) if cb[1] else None))
-        self._dev._active_window = self
+        self._dev._ck(self._dev._lib.swr_bind_framebuffer(self._dev._ctx, C.c_void_p(cb[0]) if cb[0] else None,
+                                                          C.c_void_p(cb[1]) if cb[1] else None))
+
+    def _is_active(self):
+        return getattr(self._dev, "_active_window", None) is self
 
     def Resize(self, width: int, height: int):          # HandleResize, MainWindow.cs:320-321
         self.RenderWidth, self.RenderHeight = int(width), int(height)
-        self._dev._active_window = None
-        self._activate()
+        if self._is_active():
+            self._apply_size()
+        else:
+            self._activate()
 
     def SetBand(self, first_tile_row: int, n_tile_rows: int):
         self._band = (int(first_tile_row), int(n_tile_rows)) if first_tile_row >= 0 and n_tile_rows >= 0 else None
-        self._dev._active_window = None
-        self._activate()
+        if self._is_active():
+            self._apply_band()
+        else:
+            self._activate()
 
     def SetBandInterleaved(self, rank: int, world: int, stripe_tile_rows: int):
         """Interleaved stripes instead of one contiguous band: stripe s (stripe_tile_rows tile rows) belongs to rank s % world;
         the window then holds this rank's stripes one after the other (multigpu.stripe_rows gives their frame rows)."""
         self._band = (int(rank), int(world), int(stripe_tile_rows))
-        self._dev._active_window = None
-        self._activate()
+        if self._is_active():
+            self._apply_band()
+        else:
+            self._activate()
 
     def band_pixel_rows(self):
         tiles_y = (self.RenderHeight + 15) // 16
@@ -306,9 +343,13 @@ class MainWindow:
         return y0, max(0, y1 - y0)
 
     def BindFramebuffer(self, color_ptr: int, depth_ptr: int):
+        """swr_bind_framebuffer: does not wait for the GPU.  Buffers bound earlier stay referenced until the next validating call
+        (Device.sync / read-back / stats): see the lifetime rule in include/swr.h."""
         self._bound = (int(color_ptr), int(depth_ptr)) if color_ptr and depth_ptr else None
-        self._dev._active_window = None
-        self._activate()
+        if self._is_active():
+            self._apply_binding()
+        else:
+            self._activate()
 
     def ClearColorBuffer(self, clear_color):             # MainWindow.cs:400-407
         self._activate()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     missing = [f for f in header_functions() if not hasattr(lib, f)]
     assert not missing, missing
     lib.swr_abi_version.restype = ctypes.c_int
-    assert lib.swr_abi_version() == 1
+    assert lib.swr_abi_version() == 2
 
 
 def test_struct_layouts_match_the_reference_types():

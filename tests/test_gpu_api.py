@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 
 from softwarerenderer_amd import _native as N, hostmath as hm, multigpu, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 from softwarerenderer_amd.rasterizer import (BlendMode, CullMode, DebugMode, DepthTest, MainWindow, Mesh, Program,
                                               Rasterizer, Shaders, Texture)
 from util import assert_frame_parity, render_oracle, ulp_distance
@@ -525,3 +527,60 @@ def test_async_flatten_and_deferred_validation():
     assert ulp_distance(rgb.cpu().numpy(), rc[..., :3]).max() <= 1
     r0.close(); r1.close()
     device.close()
+
+
+def test_bind_framebuffer_neither_waits_nor_resets_the_counters():
+    """the double-buffered frame loop of bench.py binds another band buffer every frame.  That must be ONE
+    swr_bind_framebuffer -- no flush-and-wait (swr_sync_count unchanged), no restart of the fragment counters -- and a resize / band
+    call that changes nothing must not wait either."""
+    import torch
+    from softwarerenderer_amd import Device, MainWindow
+    device = Device(0)
+    scene = scenes.cfg2(256, 256, 200, seed=77, min_area=20.0, max_area=400.0)
+    win = MainWindow(device, 256, 256)
+    bufs = [(torch.zeros((256, 256, 4), dtype=torch.float32, device="cuda"), torch.zeros((256, 256), dtype=torch.float32, device="cuda"))
+            for _ in range(2)]
+    win.BindFramebuffer(bufs[0][0].data_ptr(), bufs[0][1].data_ptr())
+    r = scenes.SceneRenderer(device, scene, window=win)
+    r.submit_frame(); device.sync()                                   # sizes the pair buffers
+    device.reset_stats()
+    one = None
+    s0 = device.sync_count()
+    for i in range(6):
+        win.BindFramebuffer(bufs[i & 1][0].data_ptr(), bufs[i & 1][1].data_ptr())
+        win.Resize(256, 256)                                          # unchanged geometry: no-ops on the C side
+        win.SetBand(-1, -1)
+        r.submit_frame(); device.flush()
+        assert device.sync_count() == s0, "BindFramebuffer / unchanged Resize / SetBand / flush made the host wait"
+    st = device.stats()                                               # (this one validates and waits)
+    device.reset_stats()
+    r.submit_frame(); device.flush()
+    one = device.stats()
+    assert st["fragments_tested"] == 6 * one["fragments_tested"] > 0
+    assert st["fragments_written"] == 6 * one["fragments_written"]
+    # counters also survive a real change of geometry (they move into the carry words)
+    device.reset_stats()
+    r.submit_frame(); device.flush()
+    win.SetBand(0, 8)                                                 # upper half only from now on
+    r.submit_frame(); device.flush()
+    both = device.stats()
+    assert one["fragments_tested"] < both["fragments_tested"] < 2 * one["fragments_tested"]
+    r.close(); device.close()
+
+
+def test_build_identity_matches_the_verified_pair():
+    """the lane-to-lane LDS hand-offs of k_cover / k_raster_c carry no fence (every fence form costs 25 %); they are
+    verified per (compiler, kernel source) pair by the parity suite and the sweeps.  The library says which pair it is
+    (swr_build_info) and profiles/verified_build.json holds the pair the sweeps of this round ran on."""
+    from softwarerenderer_amd import _native
+    if os.environ.get("SWR_DEV_BUILD") == "1":
+        pytest.skip("development A/B build (tools/ab/*.sh): the verified pair is recorded for the round's final build only")
+    info = _native.load().swr_build_info().decode()
+    fields = dict(kv.split("=", 1) for kv in info.split("; "))
+    assert set(fields) == {"hipcc", "csrc_sha256", "fma", "dot"} and len(fields["csrc_sha256"]) == 64
+    with open(os.path.join(ROOT, "profiles", "verified_build.json")) as f:
+        ver = json.load(f)
+    assert fields["hipcc"] == ver["hipcc"], "built with another compiler than the one the LDS hand-offs were verified with"
+    assert fields["csrc_sha256"] == ver["csrc_sha256"], "kernel sources changed since the sweeps ran: re-run tools/parity_sweep*.py and tools/record_verified_build.py"
+    if not os.environ.get("SWR_LIB"):
+        assert (fields["fma"], fields["dot"]) == ("0", "0")

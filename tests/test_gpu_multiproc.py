@@ -25,20 +25,28 @@ def _free_port():
 def test_two_ranks_on_one_gpu_store_their_bands_into_rank0s_frame(tmp_path):
     out = tmp_path / "frame.npy"
     env = dict(os.environ, SWR_BENCH_ONE_DEVICE="1", SWR_BENCH_DUMP_FRAME=str(out), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3_small", "--steps", "3",
+    # started the way the driver starts it -- `python bench.py --gpus 2 ...`, NOT under torchrun: bench.py launches its own ranks
+    # as fresh child processes (launch_ranks_if_needed) and forwards rank 0's JSON line and their exit code
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3_small", "--steps", "3",
            "--warmup", "1", "--prime", "2", "--gather", "p2p", "--backend", "gloo", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["multi_gpu"]["gather_payload"] == "p2p" and line["multi_gpu"]["frames_resent_after_replay"] == 0
+    assert line["config"]["gather_payload"] == "p2p" and line["config"]["gather_bytes_per_pixel"] == 12
+    # counters cover every timed frame although the band buffers alternate (BindFramebuffer per frame): 3 steps of the whole frame
+    assert line["fragments_tested_per_frame"] > 0 and line["value"] > 0
     # the frame rank 0 ended up with == the Vector4 -> Vector3 flatten of the single-GPU frame
     from softwarerenderer_amd import Device, scenes
     got = np.load(out)
     scene = scenes.cfg3(1024, 1024, (4, 4), (64, 32), tex_size=512)
     dev = Device(0)
     rr = scenes.SceneRenderer(dev, scene)
+    dev.reset_stats()
     c, _ = rr.render()
+    whole = dev.stats()["fragments_tested"]
     rr.close(); dev.close()
+    assert line["fragments_tested_per_frame"] == whole     # summed over both ranks and divided by the timed steps: nothing lost at a Bind
     assert got.shape == (1024, 1024, 3)
     assert np.array_equal(got.view(np.uint32), c[..., :3].view(np.uint32))

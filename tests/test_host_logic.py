@@ -1,4 +1,7 @@
-"""Host-side logic: enum ordinals, scene generators, matrix factories, band partition."""
+"""Host-side logic: enum ordinals, scene generators, matrix factories, band partition, bench.py's rank launcher."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -65,3 +68,54 @@ def test_band_partition_covers_every_tile_row_once(height, world):
         nxt += n
     assert max(n for _, n in bands) - min(n for _, n in bands) <= 1
     assert sum(multigpu.band_pixel_rows(height, b)[1] for b in bands) == height
+
+
+# ---- bench.py started directly with --gpus N launches its own ranks (the driver calls `python bench.py --gpus N ...`) ----
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("swr_bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_launches_its_own_ranks_when_started_directly(monkeypatch):
+    import argparse
+    import types
+    bench = _bench_module()
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    seen = {}
+
+    def fake_run(cmd, env=None, cwd=None):
+        seen["cmd"], seen["env"], seen["cwd"] = cmd, env, cwd
+        return types.SimpleNamespace(returncode=7)
+
+    argv = ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    rc = bench.launch_ranks_if_needed(argparse.Namespace(gpus=4, fake_world=0), argv, run=fake_run)
+    assert rc == 7                                                   # the children's exit code is the launcher's
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                                       # same arguments, after the script
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["cwd"] == ROOT
+
+
+def test_bench_does_not_launch_when_it_is_a_rank_or_single_gpu(monkeypatch):
+    import argparse
+    bench = _bench_module()
+
+    def boom(*a, **k):
+        raise AssertionError("must not launch")
+
+    for k in ("WORLD_SIZE", "RANK"):
+        monkeypatch.delenv(k, raising=False)
+    assert bench.launch_ranks_if_needed(argparse.Namespace(gpus=1, fake_world=0), [], run=boom) is None
+    assert bench.launch_ranks_if_needed(argparse.Namespace(gpus=2, fake_world=2), [], run=boom) is None
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    assert bench.launch_ranks_if_needed(argparse.Namespace(gpus=2, fake_world=0), [], run=boom) is None
