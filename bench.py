@@ -31,7 +31,7 @@ BYTES_PER_WRITTEN_FRAGMENT = 20  # 16 B float4 colour + 4 B float depth (SURVEY.
 def build_scene(name, args):
     from softwarerenderer_amd import scenes
     if name == "cfg3":
-        return scenes.cfg3()
+        return scenes.cfg3(bilinear=bool(getattr(args, "bilinear", False)))
     if name == "cfg4":
         return scenes.cfg4()
     if name == "cfg5":
@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--prime", type=int, default=32, help="untimed setup frames before warmup (runtime/buffer initialisation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bilinear", action="store_true",
+                    help="cfg3 through the BUILD-DEFINED bilinear texture filter (4 texel gathers per fragment) instead of the reference's "
+                         "nearest filter (Texture.cs:43-63); parity is against the build's own oracle definition only")
     ap.add_argument("--fake-world", type=int, default=0,
                     help="self-test of the N>1 code path in ONE process: act as rank 0 of N, collectives stubbed (numbers are meaningless)")
     ap.add_argument("--no-profile-events", action="store_true", help="do not record hipEvents around kernels in the timed region")
@@ -333,7 +336,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, {n_tris} triangles in {len(scene.draws)} u16 meshes, "
-                                   f"{'2048^2 RGBA8 nearest texture, ' if scene.textures else ''}"
+                                   f"{('2048^2 RGBA8 ' + ('bilinear (build-defined) ' if scene.bilinear else 'nearest ') + 'texture, ') if scene.textures else ''}"
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
                        "parallelism": "1 GPU" if world == 1 else (f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0" if not p2p else

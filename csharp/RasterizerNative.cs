@@ -110,6 +110,8 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_set_depth(IntPtr ctx, int x, int y, float depth);
         [DllImport(Lib)] public static extern int swr_readback(IntPtr ctx, Vector4* colorRgba, float* depth);
         [DllImport(Lib)] public static extern int swr_readback_rgb(IntPtr ctx, Vector3* rgb);
+        [DllImport(Lib)] public static extern int swr_present_rgb_async(IntPtr ctx, Vector3* rgb, out ulong ticket);
+        [DllImport(Lib)] public static extern int swr_present_wait(IntPtr ctx, ulong ticket);
         [DllImport(Lib)] public static extern int swr_flatten_rgb_device(IntPtr ctx, IntPtr deviceRgb);
         [DllImport(Lib)] public static extern int swr_flatten_rgb_device_async(IntPtr ctx, IntPtr deviceRgb);
         [DllImport(Lib)] public static extern int swr_replay_count(IntPtr ctx, out ulong replays);
@@ -145,6 +147,71 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_debug_counters(IntPtr ctx, ulong* out8);
     }
 
+    // ---------------------------------------------------------------- numerics probe ----
+    // Nothing in the reference's repository pins how .NET 9 evaluates Vector4.Transform / Vector4.Lerp (with fused multiply-adds or
+    // without) and Vector3.Dot (in which order the lanes are summed), and a third of a real frame's depth words depend on the first
+    // question (DESIGN.md section 3).  The backend is built in every model (libswr_hip.so = unfused + sequential, _fma, _dotpw,
+    // _fma_dotpw, _dpps); at start-up the three operations are evaluated with the RUNNING System.Numerics on operands on which the
+    // models give different float32 bits, and the library built for the observed model is the one `swr_hip` resolves to.  A pattern
+    // that no build models (e.g. Lerp fused but Transform not) throws: better no picture than a frame that silently differs.
+    public static class NumericsProbe
+    {
+        // <generated by tools/make_numerics_probe.py -- do not edit; tests/test_abi.py compares with csharp/numerics_probe.json>
+        const uint LerpA = 0xC00CEF08u, LerpB = 0xBED29EFEu, LerpT = 0x3F478017u, LerpUnfused = 0xBF4E7C50u, LerpFused = 0xBF4E7C4Fu;
+        static readonly uint[] TransformV = { 0xC06E43E7u, 0xC00C65BDu, 0x3EF222FCu, 0xBF9FF980u }, TransformColumn = { 0x3FA4C6C1u, 0x3F79740Cu, 0x3FC9D8E3u, 0xC06C7478u };
+        const uint TransformUnfused = 0xBFC88EB0u, TransformFused = 0xBFC88EACu;
+        static readonly uint[] DotA = { 0x404E9543u, 0xBE0E5810u, 0x3FC0BF7Cu }, DotB = { 0x3F68F07Eu, 0x3EE1EC4Bu, 0xC03AC7F0u };
+        const uint DotSequential = 0xBFC26DE8u, DotShuffle = 0xBFC26DE9u;
+        static readonly uint[] DotZeroA = { 0x80000000u, 0x80000000u, 0x80000000u }, DotZeroB = { 0x3F800000u, 0x3F800000u, 0x3F800000u };
+        const uint DotZeroSequential = 0x80000000u, DotZeroDpps = 0x00000000u;
+        // </generated>
+
+        static volatile uint salt = 0;      // read at run time, so that the JIT cannot fold the probe expressions at compile time
+        static float F(uint bits) => BitConverter.UInt32BitsToSingle(bits ^ salt);
+        static uint B(float f) => BitConverter.SingleToUInt32Bits(f);
+
+        /// (fma, dotOrder) of the running System.Numerics in the terms of swr_numerics_mode; throws on an unknown pattern.
+        [MethodImpl(MethodImplOptions.NoInlining)]
+        public static (int fma, int dotOrder) Observe()
+        {
+            uint lerp = B(Vector4.Lerp(new Vector4(F(LerpA)), new Vector4(F(LerpB)), F(LerpT)).X);
+            var m = new Matrix4x4(F(TransformColumn[0]), 0, 0, 0, F(TransformColumn[1]), 0, 0, 0, F(TransformColumn[2]), 0, 0, 0, F(TransformColumn[3]), 0, 0, 0);
+            uint tr = B(Vector4.Transform(new Vector4(F(TransformV[0]), F(TransformV[1]), F(TransformV[2]), F(TransformV[3])), m).X);
+            uint dot = B(Vector3.Dot(new Vector3(F(DotA[0]), F(DotA[1]), F(DotA[2])), new Vector3(F(DotB[0]), F(DotB[1]), F(DotB[2]))));
+            uint dz = B(Vector3.Dot(new Vector3(F(DotZeroA[0]), F(DotZeroA[1]), F(DotZeroA[2])), new Vector3(F(DotZeroB[0]), F(DotZeroB[1]), F(DotZeroB[2]))));
+            int lerpFused = lerp == LerpFused ? 1 : lerp == LerpUnfused ? 0 : -1;
+            int trFused = tr == TransformFused ? 1 : tr == TransformUnfused ? 0 : -1;
+            if (lerpFused < 0 || trFused < 0 || lerpFused != trFused)
+                throw new NotSupportedException($"System.Numerics model not built: Lerp -> 0x{lerp:X8}, Transform -> 0x{tr:X8} (see csharp/numerics_probe.json)");
+            int order;
+            if (dot == DotShuffle) order = 2;
+            else if (dot == DotSequential) order = dz == DotZeroDpps ? 1 : dz == DotZeroSequential ? 0 : -1;
+            else order = -1;
+            if (order < 0) throw new NotSupportedException($"System.Numerics model not built: Dot -> 0x{dot:X8} / 0x{dz:X8} (see csharp/numerics_probe.json)");
+            if (lerpFused == 1 && order == 1) throw new NotSupportedException("System.Numerics model not built: fused multiply-adds with the dpps dot order");
+            return (lerpFused, order);
+        }
+
+        /// File name of the build that models the running System.Numerics.
+        public static string SelectLibrary()
+        {
+            var (fma, order) = Observe();
+            string suffix = (fma == 1 ? "_fma" : "") + (order == 2 ? "_dotpw" : order == 1 ? "_dpps" : "");
+            return "libswr_hip" + suffix + ".so";
+        }
+
+        /// Makes every [DllImport("swr_hip")] of this assembly load the selected build; checks that the library agrees.
+        public static void Install()
+        {
+            string file = SelectLibrary();
+            NativeLibrary.SetDllImportResolver(typeof(NumericsProbe).Assembly, (name, assembly, path) =>
+                name == "swr_hip" ? NativeLibrary.Load(System.IO.Path.Combine(AppContext.BaseDirectory, file)) : IntPtr.Zero);
+            var (fma, order) = Observe();
+            if (Native.swr_numerics_mode(out int libFma, out int libOrder) != 0 || libFma != fma || libOrder != order)
+                throw new InvalidOperationException($"{file} was built for fma={libFma}, dot={libOrder}; the probe observed fma={fma}, dot={order}");
+        }
+    }
+
     // ---------------------------------------------------------------- context ----
     public static class SwrContext
     {
@@ -159,6 +226,7 @@ namespace SoftwareRenderer
                 lock (createLock)
                 {
                     if (ctx != IntPtr.Zero) return ctx;
+                    NumericsProbe.Install();                          // before the first P/Invoke: picks the build that models this .NET's System.Numerics
                     if (Native.swr_abi_version() != 2) throw new InvalidOperationException("libswr_hip.so: ABI version mismatch");
                     int rc = Native.swr_create(0, out IntPtr c);       // one context drives one GPU; there is NO CPU fallback
                     if (rc != 0) throw new InvalidOperationException($"swr_create failed ({rc}): {Marshal.PtrToStringAnsi(Native.swr_last_error(IntPtr.Zero))}");
@@ -327,6 +395,37 @@ namespace SoftwareRenderer
         public static void Present(Vector3[] flatColorBuffer)
         {
             fixed (Vector3* p = flatColorBuffer) SwrContext.Check(Native.swr_readback_rgb(SwrContext.Handle, p));
+        }
+        /// Double-buffered present for a host that keeps MainWindow.OnRender (MainWindow.cs:226-263): two PINNED flat buffers
+        /// alternate; PresentAsync(i) starts frame i's flatten + copy and returns the buffer of frame i - 1, which has finished
+        /// crossing PCIe while frame i was being rendered (null on the very first call).  Per frame the host then pays
+        /// max(render, copy) instead of render + copy: at 4096 x 4096 the copy is 4.6 ms and the render 0.7 ms (DESIGN.md section 5).
+        static readonly Vector3[]?[] presentBuffers = new Vector3[]?[2];
+        static readonly GCHandle[] presentPins = new GCHandle[2];
+        static readonly ulong[] presentTickets = new ulong[2];
+        static int presentNext;
+        public static Vector3[]? PresentAsync(int width, int height)
+        {
+            int cur = presentNext, prev = presentNext ^ 1;
+            presentNext = prev;
+            int n = Math.Max(width, 0) * Math.Max(height, 0);
+            if (presentBuffers[cur] == null || presentBuffers[cur]!.Length != n)
+            {
+                if (presentBuffers[cur] != null) { SwrContext.Check(Native.swr_host_unregister(SwrContext.Handle, (void*)presentPins[cur].AddrOfPinnedObject())); presentPins[cur].Free(); }
+                presentBuffers[cur] = new Vector3[n];
+                presentPins[cur] = Pin(presentBuffers[cur]!, (nuint)n * 12);
+            }
+            SwrContext.Check(Native.swr_present_rgb_async(SwrContext.Handle, (Vector3*)presentPins[cur].AddrOfPinnedObject(), out presentTickets[cur]));
+            if (presentTickets[prev] == 0) return null;
+            int rc = Native.swr_present_wait(SwrContext.Handle, presentTickets[prev]);
+            presentTickets[prev] = 0;
+            if (rc == 1)        // SWR_STALE: a batch was replayed while the pair buffers were still growing -- take that frame synchronously
+            {
+                Present(presentBuffers[prev]!);
+                return presentBuffers[prev];
+            }
+            SwrContext.Check(rc);
+            return presentBuffers[prev];
         }
         /// Full-precision read-back into the reference's own arrays (tools, screenshots).
         public static void Readback(Vector4[] colorBuffer, float[] depthBuffer)

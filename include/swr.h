@@ -34,7 +34,7 @@ extern "C" {
 #endif
 
 #define SWR_ABI_VERSION 2     /* 2: swr_bind_framebuffer no longer drains (lifetime rule below); swr_resize / swr_set_band* are no-ops when
-                               * nothing changes; new: swr_sync_count, swr_build_info, swr_numerics_mode */
+                               * nothing changes; new: swr_sync_count, swr_build_info, swr_numerics_mode, swr_present_rgb_async / swr_present_wait */
 
 /* status codes */
 #define SWR_OK                 0
@@ -43,6 +43,7 @@ extern "C" {
 #define SWR_ERR_OOM           (-3)  /* hipMalloc failed */
 #define SWR_ERR_NO_DEVICE     (-4)  /* no gfx950 device / runtime missing */
 #define SWR_ERR_UNSUPPORTED   (-5)
+#define SWR_STALE              1    /* swr_present_wait only (not an error): the copied frame predates a replayed batch, present again */
 
 /* Rasterizer.DebugMode, Rasterizer.cs:14-18 */
 enum { SWR_DEBUG_NONE = 0, SWR_DEBUG_WIREFRAME = 1 };
@@ -157,6 +158,15 @@ int  swr_readback(swr_context* ctx, float* color_rgba, float* depth);
 /* flush, then copy the colour band as packed RGB floats (12 B per pixel): the Vector4 -> Vector3 flatten of
  * MainWindow.OnRender (MainWindow.cs:234-240) done on the GPU, ready for glTexSubImage2D(RGB, FLOAT) */
 int  swr_readback_rgb(swr_context* ctx, float* rgb);
+/* ASYNCHRONOUS PRESENT (the read-back of a 4096 x 4096 frame takes 7 x as long as rendering it): flatten on the
+ * GPU behind the recorded draws and copy the band's RGB floats into `rgb` WITHOUT waiting -- the copy runs on a second stream of the
+ * context, so the next frame renders while this one crosses PCIe; two device staging buffers alternate, i.e. two presents may be
+ * in flight (a third first waits for the oldest).  `rgb` should be page-locked (swr_host_register) and must stay untouched until
+ * swr_present_wait(ticket) returns: SWR_OK = rgb holds the frame; SWR_STALE (1) = an optimistic batch was replayed meanwhile, the
+ * pixels predate it: present the frame again.  ≙ MainWindow.OnRender's upload of flatColorBuffer (MainWindow.cs:226-263), double
+ * buffered: a host loop `render i+1; present_async(i+1); wait(i); upload i` costs max(render, copy) per frame, not their sum. */
+int  swr_present_rgb_async(swr_context* ctx, float* rgb, uint64_t* ticket);
+int  swr_present_wait(swr_context* ctx, uint64_t ticket);
 /* same flatten, but into DEVICE memory supplied by the caller (band rows x W x 3 floats), enqueued after the recorded
  * draws on the context's stream and NOT synchronised: swr_sync (or the caller's own stream order) completes it.  This is
  * the present payload a multi-GPU frame gathers over xGMI (12 instead of 16 B per pixel). */

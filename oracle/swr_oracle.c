@@ -138,6 +138,12 @@ static inline float nm_lerp(float a, float b, float t) {
     return x + y;
 #endif
 }
+/* The three System.Numerics operations whose SIMD implementation nothing in the reference pins, exposed one by one: the start-up
+ * probe of csharp/RasterizerNative.cs evaluates Vector4.Transform / Vector4.Lerp / Vector3.Dot on operands chosen (by
+ * tools/make_numerics_probe.py, from these functions in every build of this file) so that the models give different bits. */
+void oswr_nm_transform4(const float v[4], const float m[16], float out[4]) { vec4_transform(v, m, out); }
+float oswr_nm_lerp(float a, float b, float t) { return nm_lerp(a, b, t); }
+float oswr_nm_dot3(const float a[3], const float b[3]) { return vec3_dot(a, b); }
 
 /* ---------- framebuffer, MainWindow.cs:378-436 ---------- */
 static inline int fb_index(const oswr_context* c, int x, int y) { return y * c->width + x; } /* :379 */

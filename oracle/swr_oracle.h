@@ -140,6 +140,10 @@ int   oswr_depth_func(int test, float new_depth, float old_depth);
 float oswr_edge_function(const float a[2], const float b[2], const float c[2]);
 int   oswr_numerics_fma(void);
 int   oswr_dot_pairwise(void);   /* SWR_DOT_PAIRWISE of this build: 0 sequential, 1 dpps order, 2 two shuffle-adds */
+/* Vector4.Transform / VectorN.Lerp / Vector3.Dot as THIS build models them (numerics start-up probe, tools/make_numerics_probe.py) */
+void  oswr_nm_transform4(const float v[4], const float m[16], float out[4]);
+float oswr_nm_lerp(float a, float b, float t);
+float oswr_nm_dot3(const float a[3], const float b[3]);
 
 /* FrustumCuller.cs (row N3 of SURVEY.md section 8f) */
 /* CalculateBoundingSphere, FrustumCuller.cs:59-151, in the serial schedule of its Parallel.For loops (one partition:

@@ -22,6 +22,7 @@ SWR_ERR_HIP = -2
 SWR_ERR_OOM = -3
 SWR_ERR_NO_DEVICE = -4
 SWR_ERR_UNSUPPORTED = -5
+SWR_STALE = 1          # swr_present_wait: not an error -- the copied frame predates a replayed batch, present again
 
 
 class SwrError(RuntimeError):
@@ -65,7 +66,7 @@ class Profile(C.Structure):
 EXPORTS = [
     "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved",
     "swr_bind_framebuffer", "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel",
-    "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_sync_count", "swr_host_register", "swr_host_unregister", "swr_upload", "swr_color_device_ptr",
+    "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_present_rgb_async", "swr_present_wait", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_sync_count", "swr_host_register", "swr_host_unregister", "swr_upload", "swr_color_device_ptr",
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
@@ -109,6 +110,8 @@ def load(name: str = None) -> C.CDLL:
         "swr_set_depth": (I, [P, I, I, F]),
         "swr_readback": (I, [P, P, P]),
         "swr_readback_rgb": (I, [P, P]),
+        "swr_present_rgb_async": (I, [P, P, C.POINTER(C.c_uint64)]),
+        "swr_present_wait": (I, [P, C.c_uint64]),
         "swr_flatten_rgb_device": (I, [P, P]),
         "swr_flatten_rgb_device_async": (I, [P, P]),
         "swr_replay_count": (I, [P, C.POINTER(C.c_uint64)]),

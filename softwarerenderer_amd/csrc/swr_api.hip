@@ -127,6 +127,14 @@ struct swr_context {
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
     unsigned long long replays = 0;           // times an optimistic batch did not fit and was replayed
     unsigned long long host_syncs = 0;        // times an entry point made the host wait for the stream (swr_sync_count)
+    // asynchronous present (swr_present_rgb_async): two device staging buffers alternate; the flatten runs on `stream`, the copy to
+    // the host on `copy_stream`, so the next frame renders while this one crosses PCIe
+    hipStream_t copy_stream = nullptr;
+    DevBuf present_buf[2];
+    hipEvent_t present_flat[2] = { nullptr, nullptr }, present_done[2] = { nullptr, nullptr };
+    uint64_t present_ticket[2] = { 0, 0 };    // ticket whose copy the slot carries (0 = none pending)
+    uint32_t present_seq[2] = { 0, 0 };       // last batch flushed before that present: retired when the copy is known to be over
+    uint64_t next_ticket = 0;
 
     int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
     std::vector<EventSpan> spans;
@@ -916,6 +924,12 @@ void swr_destroy(swr_context* c) {
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
     if (c->host_poison) (void)hipHostFree(c->host_poison);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 2; ++i) {
+        if (c->present_flat[i]) (void)hipEventDestroy(c->present_flat[i]);
+        if (c->present_done[i]) (void)hipEventDestroy(c->present_done[i]);
+        release(c->present_buf[i]);
+    }
     DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
                        &c->d_slot_tb, &c->d_want, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
                        &c->d_counters, &c->d_total, &c->d_scratch };
@@ -1045,6 +1059,63 @@ int swr_readback_rgb(swr_context* c, float* rgb) {
     SWR_HIP(c, hipGetLastError());
     SWR_HIP(c, hipMemcpyAsync(rgb, c->d_scratch.p, n * 12, hipMemcpyDeviceToHost, c->stream));
     return sync_locked(c);
+}
+
+int swr_present_rgb_async(swr_context* c, float* rgb, uint64_t* ticket) {
+    SWR_ENTER(c);
+    if (!rgb || !ticket) return fail(c, SWR_ERR_INVALID_ARG, "rgb or ticket is null");
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    const size_t n = band_pixels(c);
+    const int slot = (int)(c->next_ticket & 1ull);
+    if (!c->copy_stream) SWR_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        if (!c->present_flat[i]) SWR_HIP(c, hipEventCreateWithFlags(&c->present_flat[i], hipEventDisableTiming));
+        if (!c->present_done[i]) SWR_HIP(c, hipEventCreateWithFlags(&c->present_done[i], hipEventDisableTiming));
+    }
+    // the slot's previous copy (two presents ago) must be over before its staging buffer is overwritten: back-pressure, not
+    // steady-state waiting -- a caller that waits for ticket i before it presents frame i + 2 never blocks here
+    if (c->present_ticket[slot]) { SWR_HIP(c, hipEventSynchronize(c->present_done[slot])); c->present_ticket[slot] = 0; }
+    if (n) {
+        if (c->present_buf[slot].cap < n * 12) {
+            // growing frees the old block: make sure neither stream still uses it (first frame / after a resize only)
+            SWR_HIP(c, hipStreamSynchronize(c->copy_stream));
+            if ((rc = ensure(c, c->present_buf[slot], n * 12))) return rc;
+        }
+        const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
+        hipLaunchKernelGGL(k_flatten_rgb, dim3(blocks), dim3(256), 0, c->stream, (const float4*)c->color, c->present_buf[slot].as<float>(), n);
+        SWR_HIP(c, hipGetLastError());
+    }
+    SWR_HIP(c, hipEventRecord(c->present_flat[slot], c->stream));
+    SWR_HIP(c, hipStreamWaitEvent(c->copy_stream, c->present_flat[slot], 0));
+    if (n) SWR_HIP(c, hipMemcpyAsync(rgb, c->present_buf[slot].p, n * 12, hipMemcpyDeviceToHost, c->copy_stream));
+    SWR_HIP(c, hipEventRecord(c->present_done[slot], c->copy_stream));
+    c->present_ticket[slot] = ++c->next_ticket;
+    c->present_seq[slot] = c->next_seq - 1u;
+    *ticket = c->present_ticket[slot];
+    return SWR_OK;
+}
+
+int swr_present_wait(swr_context* c, uint64_t ticket) {
+    SWR_ENTER(c);
+    int slot = -1;
+    for (int i = 0; i < 2; ++i) if (c->present_ticket[i] == ticket && ticket) slot = i;
+    if (slot < 0) return ticket && ticket <= c->next_ticket ? SWR_OK : fail(c, SWR_ERR_INVALID_ARG, "unknown present ticket");   // already waited for
+    SWR_HIP(c, hipEventSynchronize(c->present_done[slot]));
+    c->present_ticket[slot] = 0;
+    if (*(volatile uint32_t*)c->host_poison) {
+        // a batch did not fit its pair buffers and poisoned itself (and everything after it): the copied pixels predate it.
+        // Drain, replay (validate_locked) and tell the caller to present again.
+        int rc = sync_locked(c);
+        return rc ? rc : SWR_STALE;
+    }
+    // every batch flushed before this present has completed (the flatten ran behind them): retire them without draining the stream
+    const uint32_t upto = c->present_seq[slot];
+    size_t k = 0;
+    while (k < c->inflight.size() && c->inflight[k].seq <= upto) { retire_batch(c, c->inflight[k]); ++k; }
+    c->inflight.erase(c->inflight.begin(), c->inflight.begin() + (std::ptrdiff_t)k);
+    free_garbage(c);
+    return SWR_OK;
 }
 
 int swr_host_register(swr_context* c, void* ptr, size_t bytes) {

@@ -38,7 +38,21 @@ namespace swr {
 // cache, 28 in the DUST2 kernel) into vector loads (16 left) with a vmcnt(0) wait in every chunk: k_raster_c 0.46 -> 0.58 ms
 // on cfg3 (gpurun_out/ab_r02j.txt).  An `asm volatile` block in the batch loop has the same kind of cost (it drains the
 // window prefetch at the loop top): wave_min's DPP ladder is a plain `asm` for that reason.
+// What makes this safe to ship is verification, not the memory model: (1) libswr_hip_test.so is built with SWR_WAVE_LDS_FENCE --
+// a real wavefront-scope release / wave_barrier / acquire at every hand-off -- and tests/test_gpu_testlib.py requires its frames to
+// equal the unfenced product's bit for bit; (2) tests/test_lds_handoff_asm.py disassembles the product build and checks that at
+// each hand-off the ds_write / returning atomic precedes the dependent ds_read in the emitted code; (3) swr_build_info() names the
+// compiler and source hash, and tests/test_gpu_api.py compares them with the pair the sweeps ran on (profiles/verified_build.json).
+// The one COLD hand-off (k_cover's widest-box exchange, once per 256 pairs) carries the real fence in every build.
+#define SWR_WAVE_LDS_FENCE_REAL() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                                       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#ifndef SWR_WAVE_LDS_SYNC
+#ifdef SWR_WAVE_LDS_FENCE
+#define SWR_WAVE_LDS_SYNC() SWR_WAVE_LDS_FENCE_REAL()
+#else
 #define SWR_WAVE_LDS_SYNC() ((void)0)
+#endif
+#endif
 
 // wave64 ballot straight from a bool: HIP's __ballot(int) first materialises the predicate as 0 / 1 in a VGPR and compares it
 // with zero again (two VALU instructions per use); the builtin takes the condition mask as it is
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
                 // never looked at (colmask) and stay finite (<= 31 adds of values below 1e30).
                 const int width = endX - startX + 1;
                 atomicMax(&s_wmax[threadIdx.x >> 6], (uint32_t)width);
-                SWR_WAVE_LDS_SYNC();
+                SWR_WAVE_LDS_FENCE_REAL();        // cold (once per lane and 256-pair block): the real fence costs nothing measurable here
                 const int wsteps = __builtin_amdgcn_readfirstlane((int)s_wmax[threadIdx.x >> 6]);
                 const uint32_t colmask = (1u << width) - 1u;
                 const int sh = startX - x0;

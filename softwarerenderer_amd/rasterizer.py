@@ -393,6 +393,28 @@ class MainWindow:
             self._dev._ck(self._dev._lib.swr_readback_rgb(self._dev._ctx, out.ctypes.data))
         return out
 
+    def PresentAsync(self, out: np.ndarray) -> int:
+        """Asynchronous FlatColorBuffer (swr_present_rgb_async): flatten on the GPU behind the recorded draws, copy into `out`
+        (page-lock it with Device.pin()) on the context's copy stream, return a ticket at once.  The next frame renders while this
+        one crosses PCIe; `out` must stay untouched until PresentWait(ticket)."""
+        _, rows = self.band_pixel_rows()
+        shape = (rows, max(self.RenderWidth, 0), 3)
+        if out.shape != shape or out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {shape}")
+        self._activate()
+        t = C.c_uint64(0)
+        self._dev._ck(self._dev._lib.swr_present_rgb_async(self._dev._ctx, C.c_void_p(out.ctypes.data), C.byref(t)))
+        return int(t.value)
+
+    def PresentWait(self, ticket: int) -> bool:
+        """Blocks until the present `ticket` has landed in its array.  True = the array holds the frame; False = a batch was replayed
+        meanwhile (SWR_STALE: only while the pair buffers are still growing), present that frame again."""
+        rc = self._dev._lib.swr_present_wait(self._dev._ctx, C.c_uint64(ticket))
+        if rc == N.SWR_STALE:
+            return False
+        self._dev._ck(rc)
+        return True
+
     def FlattenTo(self, device_ptr: int):
         """FlatColorBuffer into caller-owned DEVICE memory (band rows x W x 3 floats); completes with Device.sync()."""
         self._activate()

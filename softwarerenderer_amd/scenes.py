@@ -152,9 +152,11 @@ def _patch_mesh(rng, nx, ny, centre_ndc, half_ndc, z_near, z_far, inv_vp, uv_lo=
 
 
 def cfg3(width=4096, height=4096, grid=(4, 4), quads=(250, 125), seed=2, tex_size=2048,
-         program=Program.Dust2LambertFog, name=None) -> Scene:
+         program=Program.Dust2LambertFog, name=None, bilinear=False) -> Scene:
     """grid[0]*grid[1] indexed patches of quads[0]*quads[1]*2 triangles each (default 16 x 62,500 = 1M),
-    overlapping with depth complexity about 3, one random RGBA8 texture, UVs in [-2,3] (wrap)."""
+    overlapping with depth complexity about 3, one random RGBA8 texture, UVs in [-2,3] (wrap).
+    bilinear=True: the same frame through the BUILD-DEFINED bilinear filter (BASELINE.json words cfg3 as "bilinear-textured"; the
+    reference's Texture.Sample is nearest, Texture.cs:43-63, which stays the default and the benchmark's configuration)."""
     rng = np.random.default_rng(seed)
     proj = _perspective(width, height)
     model = hm.create_scale(0.5)                                     # Renderer.cs:32 ModelMatrix
@@ -185,7 +187,8 @@ def cfg3(width=4096, height=4096, grid=(4, 4), quads=(250, 125), seed=2, tex_siz
         draws.append(Draw(v, idx, model, view, proj, program=program, uniforms=uni, texture=0,
                           cull=CullMode.Back, depth_test=DepthTest.LessEqual, blend=BlendMode.Alpha))
     n = gx * gy * quads[0] * quads[1] * 2
-    return Scene(name or f"cfg3_{width}x{height}_{n}", width, height, draws, textures=[tex])
+    return Scene(name or f"cfg3_{width}x{height}_{n}" + ("_bilinear" if bilinear else ""), width, height, draws, textures=[tex],
+                 bilinear=bool(bilinear))
 
 
 def cfg4(**kw) -> Scene:

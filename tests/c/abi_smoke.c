@@ -13,7 +13,7 @@
 #define RESOLVE(name) do { *(void**)(&p_##name) = dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; } } while (0)
 
 static const char* const all_symbols[] = {
-    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_sync_count", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved", "swr_bind_framebuffer",
+    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_sync_count", "swr_present_rgb_async", "swr_present_wait", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved", "swr_bind_framebuffer",
     "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel", "swr_set_pixel", "swr_get_depth", "swr_set_depth",
     "swr_readback", "swr_readback_rgb", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_host_register", "swr_host_unregister", "swr_upload",
     "swr_color_device_ptr", "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter",

@@ -21,7 +21,10 @@ sys.path.insert(0, ROOT)
 from oracle import binding as ob                      # noqa: E402
 from softwarerenderer_amd import scenes               # noqa: E402
 
-CONFIGS = {"cfg2": (scenes.cfg2, 120), "cfg3": (scenes.cfg3, 512), "cfg4": (scenes.cfg4, 512), "cfg5": (scenes.cfg5, 1024)}
+CONFIGS = {"cfg2": (scenes.cfg2, 120), "cfg3": (scenes.cfg3, 512), "cfg4": (scenes.cfg4, 512), "cfg5": (scenes.cfg5, 1024),
+           # cfg3 through the BUILD-DEFINED bilinear filter (BASELINE.json says "bilinear-textured"; the reference samples nearest):
+           # pinned to the build's own definition only (oracle/swr_oracle.c:oswr_texture_sample_bilinear)
+           "cfg3_bilinear": (lambda: scenes.cfg3(bilinear=True), 512)}
 
 
 def sha(a):

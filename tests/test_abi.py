@@ -155,3 +155,79 @@ def test_csharp_shim_keeps_the_reference_signature_and_enum_ordinals():
     for fwd in ("SetPixel", "GetPixel", "ClearColorBuffer", "SetDepth", "GetDepth", "ClearDepthBuffer", "Resize", "Present"):
         assert re.search(r"public static \w+ %s\(" % fwd, CS), fwd          # MainWindow.cs:320-321,382-436 forwards
     assert "class TextureNative : IDisposable" in CS and "public Vector4 Sample(Vector2 uv)" in CS and "public void Dispose()" in CS
+
+
+# ---- numerics start-up probe (csharp/RasterizerNative.cs NumericsProbe, tools/make_numerics_probe.py) ----
+def _probe_models():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_numerics_probe", os.path.join(ROOT, "tools", "make_numerics_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, mod.models()
+
+
+def _observe(mod, lib, probes):
+    """What NumericsProbe.Observe() computes, with ONE oracle build standing in for the running System.Numerics."""
+    import struct
+    f = lambda b: struct.unpack("<f", struct.pack("<I", b))[0]
+    p = probes
+    return {"lerp": mod.lerp(lib, f(p["lerp"]["a"]), f(p["lerp"]["b"]), f(p["lerp"]["t"])),
+            "transform": mod.transform_x(lib, [f(x) for x in p["transform"]["v"]], [f(x) for x in p["transform"]["column"]]),
+            "dot": mod.dot(lib, [f(x) for x in p["dot"]["a"]], [f(x) for x in p["dot"]["b"]]),
+            "dot_zero": mod.dot(lib, [f(x) for x in p["dot_zero"]["a"]], [f(x) for x in p["dot_zero"]["b"]])}
+
+
+def _select(obs, p):
+    """NumericsProbe.SelectLibrary(): the decision tree of the C# file, restated."""
+    lerp = 1 if obs["lerp"] == p["lerp"]["fused"] else 0 if obs["lerp"] == p["lerp"]["unfused"] else -1
+    tr = 1 if obs["transform"] == p["transform"]["fused"] else 0 if obs["transform"] == p["transform"]["unfused"] else -1
+    assert lerp >= 0 and tr >= 0 and lerp == tr
+    if obs["dot"] == p["dot"]["shuffle"]:
+        order = 2
+    else:
+        assert obs["dot"] == p["dot"]["sequential"]
+        order = 1 if obs["dot_zero"] == p["dot_zero"]["dpps"] else 0
+        assert order == 1 or obs["dot_zero"] == p["dot_zero"]["sequential"]
+    return lerp, order, "libswr_hip" + ("_fma" if lerp else "") + ("_dotpw" if order == 2 else "_dpps" if order == 1 else "") + ".so"
+
+
+def test_numerics_probe_table_selects_the_matching_build_for_every_model():
+    import json
+    mod, models = _probe_models()
+    table = json.load(open(os.path.join(ROOT, "csharp", "numerics_probe.json")))
+    p = table["probes"]
+    # the committed operands still separate the models (the expected bits are what the oracle builds compute today)
+    assert p["lerp"]["fused"] != p["lerp"]["unfused"] and p["transform"]["fused"] != p["transform"]["unfused"]
+    assert p["dot"]["sequential"] != p["dot"]["shuffle"] and p["dot_zero"]["sequential"] != p["dot_zero"]["dpps"]
+    libs = {(e["fma"], e["dot"]): e["library"] for e in table["libraries"]}
+    assert set(libs) == set(models)                                        # five builds, five models
+    for (fma, dot), olib in models.items():
+        fma_sel, dot_sel, name = _select(_observe(mod, olib, p), p)
+        assert (fma_sel, dot_sel) == (fma, dot) and name == libs[(fma, dot)]
+        path = os.path.join(ROOT, "softwarerenderer_amd", name)
+        assert os.path.exists(path), f"{name} is missing: make -C softwarerenderer_amd/csrc variants"
+        hip = ctypes.CDLL(path)                                            # loads without a GPU; the query touches no device
+        a, b = ctypes.c_int(-1), ctypes.c_int(-1)
+        assert hip.swr_numerics_mode(ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value, b.value) == (fma, dot)
+
+
+def test_csharp_probe_constants_are_the_generated_ones():
+    import json
+    p = json.load(open(os.path.join(ROOT, "csharp", "numerics_probe.json")))["probes"]
+    cs = open(os.path.join(ROOT, "csharp", "RasterizerNative.cs")).read()
+    block = re.search(r"// <generated by tools/make_numerics_probe\.py.*?// </generated>", cs, flags=re.S).group(0)
+    consts = {k: int(v, 16) for k, v in re.findall(r"(\w+) = (0x[0-9A-F]{8})u", block)}
+    arrays = {k: [int(x, 16) for x in re.findall(r"0x[0-9A-F]{8}", v)] for k, v in re.findall(r"(\w+) = \{([^}]*)\}", block)}
+    assert (consts["LerpA"], consts["LerpB"], consts["LerpT"], consts["LerpUnfused"], consts["LerpFused"]) == \
+        (p["lerp"]["a"], p["lerp"]["b"], p["lerp"]["t"], p["lerp"]["unfused"], p["lerp"]["fused"])
+    assert arrays["TransformV"] == p["transform"]["v"] and arrays["TransformColumn"] == p["transform"]["column"]
+    assert (consts["TransformUnfused"], consts["TransformFused"]) == (p["transform"]["unfused"], p["transform"]["fused"])
+    assert arrays["DotA"] == p["dot"]["a"] and arrays["DotB"] == p["dot"]["b"]
+    assert (consts["DotSequential"], consts["DotShuffle"]) == (p["dot"]["sequential"], p["dot"]["shuffle"])
+    assert arrays["DotZeroA"] == p["dot_zero"]["a"] and arrays["DotZeroB"] == p["dot_zero"]["b"]
+    assert (consts["DotZeroSequential"], consts["DotZeroDpps"]) == (p["dot_zero"]["sequential"], p["dot_zero"]["dpps"])
+    # the probe runs before the first P/Invoke, and the resolver maps the DllImport name to the selected file
+    assert "NumericsProbe.Install();" in cs and 'SetDllImportResolver' in cs and 'name == "swr_hip"' in cs
+    # regenerating gives the committed table (the search is seeded)
+    mod, _ = _probe_models()
+    assert mod.search() == p

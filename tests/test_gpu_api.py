@@ -584,3 +584,70 @@ def test_build_identity_matches_the_verified_pair():
     assert fields["csrc_sha256"] == ver["csrc_sha256"], "kernel sources changed since the sweeps ran: re-run tools/parity_sweep*.py and tools/record_verified_build.py"
     if not os.environ.get("SWR_LIB"):
         assert (fields["fma"], fields["dot"]) == ("0", "0")
+
+
+def test_asynchronous_present_overlaps_and_delivers_exact_frames():
+    """swr_present_rgb_async / swr_present_wait -- the present payload (Vector4 -> Vector3 flatten, MainWindow.cs:234-240)
+    of frame i crosses PCIe on the context's copy stream while frame i + 1 renders.  Two frames in flight, each array must hold
+    exactly its own frame; nothing on the way makes the host wait except swr_present_wait itself."""
+    from softwarerenderer_amd import Device
+    dev = Device(0)
+    a = scenes.cfg3(512, 384, (2, 2), (30, 20), tex_size=64, seed=91)
+    b = scenes.cfg2(512, 384, 1500, seed=92)
+    ra = scenes.SceneRenderer(dev, a)
+    rb = scenes.SceneRenderer(dev, b, window=ra.window)
+    want_a = ra.render()[0][..., :3].copy()                           # synchronous frames first: sizes the pair buffers too
+    want_b = rb.render()[0][..., :3].copy()
+    bufs = [np.zeros((384, 512, 3), dtype=np.float32) for _ in range(2)]
+    for x in bufs:
+        dev.pin(x)
+    try:
+        s0 = dev.sync_count()
+        ra.submit_frame(); t0 = ra.window.PresentAsync(bufs[0])
+        rb.submit_frame(); t1 = ra.window.PresentAsync(bufs[1])       # frame b renders and is flattened while frame a is copied
+        assert dev.sync_count() == s0                                 # neither present made the host wait for the stream
+        assert ra.window.PresentWait(t0) and ra.window.PresentWait(t1)
+        assert np.array_equal(bufs[0].view(np.uint32), want_a.view(np.uint32))
+        assert np.array_equal(bufs[1].view(np.uint32), want_b.view(np.uint32))
+        # a steady loop: present i, wait i - 1; every array ends up with the frame that was current at its present
+        tickets = [None, None]
+        for i in range(6):
+            (ra if i % 2 == 0 else rb).submit_frame()
+            k = i & 1
+            if tickets[k] is not None:
+                assert ra.window.PresentWait(tickets[k])
+                assert np.array_equal(bufs[k].view(np.uint32), (want_a if k == 0 else want_b).view(np.uint32))
+            tickets[k] = ra.window.PresentAsync(bufs[k])
+        for k in (0, 1):
+            assert ra.window.PresentWait(tickets[k])
+        assert ra.window.PresentWait(tickets[0])                      # waiting twice for a ticket is harmless
+    finally:
+        for x in bufs:
+            dev.unpin(x)
+    ra.close(); rb.close(); dev.close()
+
+
+def test_asynchronous_present_reports_a_stale_frame_after_a_replay():
+    """The optimistic flush of a batch that does not fit poisons itself; an asynchronous present enqueued behind it copies the
+    UNCHANGED framebuffer.  swr_present_wait must say so (SWR_STALE -> False) after replaying, and presenting again gives the frame."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    dev = Device(0)                                                   # a fresh context: its pair buffers start empty
+    small = scenes.cfg2(256, 256, 40, seed=60, min_area=10.0, max_area=60.0)
+    big = scenes.cfg2(256, 256, 3000, seed=61, min_area=200.0, max_area=9000.0)
+    o = OracleRenderer(256, 256)
+    rc, _ = o.render_scene(big)
+    o.close()
+    r0 = scenes.SceneRenderer(dev, small)
+    r0.render()                                                       # synchronous sizing of the pair buffers (small)
+    r1 = scenes.SceneRenderer(dev, big, window=r0.window)
+    out = np.zeros((256, 256, 3), dtype=np.float32)
+    before = dev.replay_count()
+    r1.submit_frame()                                                 # does not fit: poisoned on the device
+    t = r0.window.PresentAsync(out)
+    assert r0.window.PresentWait(t) is False                          # stale, and the batch has been replayed by now
+    assert dev.replay_count() == before + 1
+    t = r0.window.PresentAsync(out)                                   # the caller's reaction: present again
+    assert r0.window.PresentWait(t) is True
+    assert ulp_distance(out, rc[..., :3]).max() <= 1
+    r0.close(); r1.close(); dev.close()

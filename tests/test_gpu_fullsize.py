@@ -21,7 +21,8 @@ from util import assert_frame_parity, render_oracle
 pytestmark = pytest.mark.gpu
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_golden.json")))
-MAKERS = {"cfg2": scenes.cfg2, "cfg3": scenes.cfg3, "cfg4": scenes.cfg4, "cfg5": scenes.cfg5}
+MAKERS = {"cfg2": scenes.cfg2, "cfg3": scenes.cfg3, "cfg4": scenes.cfg4, "cfg5": scenes.cfg5,
+          "cfg3_bilinear": lambda: scenes.cfg3(bilinear=True)}      # build-defined filter: parity against the build's own oracle only
 COUNTERS = ("triangles_in", "triangles_setup", "triangles_clipped", "fragments_tested", "fragments_shaded", "fragments_written")
 
 
@@ -59,7 +60,7 @@ def full(device):
     r.close()
 
 
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5", "cfg3_bilinear"])
 def test_fullsize_golden(device, full, name):
     if name == "cfg3":
         scene, _, (c, d), _, st = full

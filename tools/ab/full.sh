@@ -14,4 +14,6 @@ for c in ("cfg3","cfg2","cfg4","cfg5"):
         if m: d=json.loads(m.group(2)); print('  ', m.group(1)[:60].ljust(60), ' '.join(f"{k[:-3]}={v}" for k,v in d.items()))
         else: print(ln.rstrip()[:200])
 P
+
+python bench.py --config cfg3 --bilinear --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_${TAG}_bilinear.json 2> gpurun_out/bench_${TAG}_bilinear.err; tail -c 1200 gpurun_out/bench_${TAG}_bilinear.json
 exit $RC

@@ -2,7 +2,8 @@
 """Timing-only A/B of kernel variants: for each EXTRA flag set, rebuild the library, run N frames of a config and print
 per-stage hipEvent times.  Outputs of ablated builds are wrong by design; the tracked library is restored afterwards.
 usage: ablate.py cfg3 "" "-DSWR_ABLATE_PHASE2" "lib:build_ab/ref.so" ...
-A variant "lib:PATH" times a prebuilt library instead (boxes differ by a few percent: keep a reference library in
+A variant "env:NAME=VALUE[,..]" times the in-tree library as it is under those environment variables (run-time switches such as
+SWR_RASTER_GRID).  A variant "lib:PATH" times a prebuilt library instead (boxes differ by a few percent: keep a reference library in
 build_ab/ -- git-ignored, but it travels with gpurun -- and compare inside ONE call)."""
 import os, shutil, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -27,6 +28,8 @@ try:
     for v in variants:
         env = dict(os.environ)
         if v.startswith("lib:"): env["SWR_ABLATE_LIB"] = os.path.join(ROOT, v[4:])
+        elif v.startswith("env:"):       # "env:NAME=VALUE,NAME2=VALUE2": the in-tree library as it is, run under these variables
+            env.update(kv.split("=", 1) for kv in v[4:].split(","))
         else: subprocess.run(["make", "-C", csrc, "-s", "-B", f"EXTRA={v}"], check=True, stderr=subprocess.DEVNULL)
         out = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, env=env)
         print(f"{v or '(release)':40s}", out.stdout.strip() or out.stderr[-400:])

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates the numerics start-up probe of csharp/RasterizerNative.cs (VERDICT r2 "Next" #3).
+
+Nothing in the reference pins how .NET 9's System.Numerics evaluates Vector4.Transform / Vector4.Lerp (fused multiply-adds or
+not: SWR_NUMERICS_FMA) and Vector3.Dot (order of the lane sum: SWR_DOT_PAIRWISE 0 sequential, 1 dpps, 2 shuffle-adds), and a
+third of cfg3's depth words depend on the first question.  Every model is built on both sides
+(libswr_hip{,_fma,_dotpw,_fma_dotpw,_dpps}.so, oracle/liboswr*.so).  This script searches, with the ORACLE builds as the models,
+operands on which the models give different float32 bits:
+    lerp      a, b, t            Vector4.Lerp(a, b, t).X            fused != unfused
+    transform v, column of M     Vector4.Transform(v, M).X          fused != unfused
+    dot       a, b               Vector3.Dot(a, b)                  shuffle-adds != sequential
+    dot_zero  a, b               Vector3.Dot(a, b) (a signed zero)  dpps != sequential (they differ in the sign of a zero only)
+and writes them with the expected bit patterns to csharp/numerics_probe.json and into the generated block of
+csharp/RasterizerNative.cs, whose NumericsProbe.SelectLibrary() evaluates the same expressions with the running .NET, compares the
+bits and loads the matching library (or throws on a pattern no build models).  tests/test_abi.py re-derives every expected bit
+pattern from the oracle builds and checks the C# constants against the JSON.   usage: python tools/make_numerics_probe.py"""
+import ctypes as C
+import json
+import os
+import re
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob       # noqa: E402   (test infrastructure: this script is a generator, not product code)
+
+LIBS = {(0, 0): "libswr_hip.so", (1, 0): "libswr_hip_fma.so", (0, 2): "libswr_hip_dotpw.so", (1, 2): "libswr_hip_fma_dotpw.so",
+        (0, 1): "libswr_hip_dpps.so"}
+ORACLES = {(0, 0): "", (1, 0): "fma", (0, 2): "dotpw", (1, 2): "fma_dotpw", (0, 1): "dpps"}
+
+
+def bits(x):
+    return struct.unpack("<I", struct.pack("<f", float(np.float32(x))))[0]
+
+
+def models():
+    out = {}
+    for key, variant in ORACLES.items():
+        lib = ob.load(variant=variant)
+        lib.oswr_nm_lerp.restype = C.c_float; lib.oswr_nm_lerp.argtypes = [C.c_float] * 3
+        lib.oswr_nm_dot3.restype = C.c_float; lib.oswr_nm_dot3.argtypes = [C.POINTER(C.c_float)] * 2
+        lib.oswr_nm_transform4.restype = None; lib.oswr_nm_transform4.argtypes = [C.POINTER(C.c_float)] * 3
+        assert (lib.oswr_numerics_fma(), lib.oswr_dot_pairwise()) == key
+        out[key] = lib
+    return out
+
+
+def lerp(lib, a, b, t):
+    return bits(lib.oswr_nm_lerp(a, b, t))
+
+
+def dot(lib, a, b):
+    fa = (C.c_float * 3)(*a); fb = (C.c_float * 3)(*b)
+    return bits(lib.oswr_nm_dot3(fa, fb))
+
+
+def transform_x(lib, v, col):
+    m = [0.0] * 16
+    for i in range(4):
+        m[4 * i] = col[i]                     # M11, M21, M31, M41: the column that makes the result's X
+    fv = (C.c_float * 4)(*v); fm = (C.c_float * 16)(*m); fo = (C.c_float * 4)()
+    lib.oswr_nm_transform4(fv, fm, fo)
+    return bits(fo[0])
+
+
+def search():
+    M = models()
+    rng = np.random.default_rng(20251004)
+    f32 = lambda n: rng.uniform(0.1, 4.0, n).astype(np.float32) * rng.choice(np.array([-1.0, 1.0], dtype=np.float32), n)
+    probe = {}
+    while "lerp" not in probe:
+        a, b = (float(x) for x in f32(2)); t = float(np.float32(rng.uniform(0.05, 0.95)))
+        u, f = lerp(M[(0, 0)], a, b, t), lerp(M[(1, 0)], a, b, t)
+        if u != f:
+            probe["lerp"] = {"a": bits(a), "b": bits(b), "t": bits(t), "unfused": u, "fused": f}
+    while "transform" not in probe:
+        v = [float(x) for x in f32(4)]; col = [float(x) for x in f32(4)]
+        u, f = transform_x(M[(0, 0)], v, col), transform_x(M[(1, 0)], v, col)
+        if u != f:
+            probe["transform"] = {"v": [bits(x) for x in v], "column": [bits(x) for x in col], "unfused": u, "fused": f}
+    while "dot" not in probe:
+        a = [float(x) for x in f32(3)]; b = [float(x) for x in f32(3)]
+        s, sh = dot(M[(0, 0)], a, b), dot(M[(0, 2)], a, b)
+        if s != sh and dot(M[(0, 1)], a, b) == s:
+            probe["dot"] = {"a": [bits(x) for x in a], "b": [bits(x) for x in b], "sequential": s, "shuffle": sh}
+    a, b = [-0.0, -0.0, -0.0], [1.0, 1.0, 1.0]          # (-0 + -0) + -0 = -0, but (-0 + -0) + (-0 + 0) = -0 + +0 = +0
+    s, dp, sh = dot(M[(0, 0)], a, b), dot(M[(0, 1)], a, b), dot(M[(0, 2)], a, b)
+    assert s == 0x80000000 and dp == 0 and sh == 0, (hex(s), hex(dp), hex(sh))
+    probe["dot_zero"] = {"a": [bits(x) for x in a], "b": [bits(x) for x in b], "sequential": s, "dpps": dp, "shuffle": sh}
+    # the fused builds must agree with the unfused ones on the dot probes (the dot models carry no multiply-add)
+    assert dot(M[(1, 0)], [struct.unpack("<f", struct.pack("<I", x))[0] for x in probe["dot"]["a"]],
+               [struct.unpack("<f", struct.pack("<I", x))[0] for x in probe["dot"]["b"]]) == probe["dot"]["sequential"]
+    return probe
+
+
+def csharp_block(p):
+    h = lambda x: "0x%08Xu" % x
+    arr = lambda xs: "{ " + ", ".join(h(x) for x in xs) + " }"
+    lines = [
+        "        // <generated by tools/make_numerics_probe.py -- do not edit; tests/test_abi.py compares with csharp/numerics_probe.json>",
+        f"        const uint LerpA = {h(p['lerp']['a'])}, LerpB = {h(p['lerp']['b'])}, LerpT = {h(p['lerp']['t'])}, LerpUnfused = {h(p['lerp']['unfused'])}, LerpFused = {h(p['lerp']['fused'])};",
+        f"        static readonly uint[] TransformV = {arr(p['transform']['v'])}, TransformColumn = {arr(p['transform']['column'])};",
+        f"        const uint TransformUnfused = {h(p['transform']['unfused'])}, TransformFused = {h(p['transform']['fused'])};",
+        f"        static readonly uint[] DotA = {arr(p['dot']['a'])}, DotB = {arr(p['dot']['b'])};",
+        f"        const uint DotSequential = {h(p['dot']['sequential'])}, DotShuffle = {h(p['dot']['shuffle'])};",
+        f"        static readonly uint[] DotZeroA = {arr(p['dot_zero']['a'])}, DotZeroB = {arr(p['dot_zero']['b'])};",
+        f"        const uint DotZeroSequential = {h(p['dot_zero']['sequential'])}, DotZeroDpps = {h(p['dot_zero']['dpps'])};",
+        "        // </generated>",
+    ]
+    return "\n".join(lines)
+
+
+def main():
+    p = search()
+    table = [{"fma": k[0], "dot": k[1], "library": v} for k, v in sorted(LIBS.items())]
+    out = {"generator": "tools/make_numerics_probe.py", "probes": p, "libraries": table}
+    with open(os.path.join(ROOT, "csharp", "numerics_probe.json"), "w") as f:
+        json.dump(out, f, indent=1); f.write("\n")
+    cs = os.path.join(ROOT, "csharp", "RasterizerNative.cs")
+    s = open(cs).read()
+    block = csharp_block(p)
+    s2, n = re.subn(r"        // <generated by tools/make_numerics_probe\.py.*?// </generated>", lambda m: block, s, flags=re.S)
+    if n != 1:
+        raise SystemExit("csharp/RasterizerNative.cs has no generated block to replace")
+    open(cs, "w").write(s2)
+    print(json.dumps(p))
+
+
+if __name__ == "__main__":
+    main()
