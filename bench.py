@@ -377,6 +377,9 @@ def main():
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": stage_ms,
             }
+            vf = valu_floor(args.config, world, raster_ms, written_local)
+            if vf is not None:
+                out["roofline"]["valu_floor"] = vf
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, renderer, np)
         print(json.dumps(out), flush=True)
@@ -441,6 +444,40 @@ def pmc_traffic(config, world):
     cor = (2.0 * t["fetch_kib_raw"] + t["write_kib"]) * 1024 / 1e9
     return round(cor, 4), {"file": os.path.basename(cands[-1]), "fetch_raw_gb": round(t["fetch_kib_raw"] * 1024 / 1e9, 4),
                            "write_gb": round(t["write_kib"] * 1024 / 1e9, 4), "raw_sum_gb": round(raw, 4)}
+
+
+NUM_SIMDS = 1024               # MI355X: 256 CUs x 4 SIMD-32
+VALU_ISSUE_CYCLES = 2          # a wave64 VALU instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md)
+PEAK_CLOCK_GHZ = 2.4
+REFERENCE_VALU_PER_64_FRAGMENTS = 215      # Interpolate + Renderer.FragmentShader + Blend, counted in the ISA: no
+                                           # multiply-add of the reference may be fused, every division and square root is IEEE
+
+
+def valu_floor(config, world, raster_ms, written_per_launch):
+    """The issue-bound floor of the dominant kernel next to its HBM roofline (the gap is issue efficiency x instruction
+    overhead, not bytes): wave-level VALU instructions per launch from the committed SQ pass of THIS build (same source-hash rule as
+    pmc_traffic) x 2 cycles / 1024 SIMDs / clock.  `reference_only_ms` is the same arithmetic for the reference's own unfusable
+    float work alone (215 VALU per 64 written fragments)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if world != 1 or not cands:
+        return None
+    j = json.load(open(cands[-1]))
+    t = j.get(config)
+    if not t or "valu_wave_insts" not in t or j.get("csrc_sha256") != kernel_source_hash():
+        return None
+    v = t["valu_wave_insts"]
+    ms = v * VALU_ISSUE_CYCLES / NUM_SIMDS / (PEAK_CLOCK_GHZ * 1e9) * 1e3
+    ref_ms = written_per_launch / 64.0 * REFERENCE_VALU_PER_64_FRAGMENTS * VALU_ISSUE_CYCLES / NUM_SIMDS / (PEAK_CLOCK_GHZ * 1e9) * 1e3
+    out = {"valu_wave_insts_per_launch": v, "ms_at_full_issue": round(ms, 4), "issue_efficiency": round(ms / raster_ms, 4),
+           "valu_per_64_written_fragments": round(v / (written_per_launch / 64.0), 1),
+           "reference_only_valu_per_64_fragments": REFERENCE_VALU_PER_64_FRAGMENTS, "reference_only_ms": round(ref_ms, 4),
+           "hbm_frac_if_issue_bound": round(written_per_launch * BYTES_PER_WRITTEN_FRAGMENT / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "unit": "wave64 VALU instructions x 2 cycles / 1024 SIMD-32 / 2.4 GHz",
+           "other_wave_insts_per_launch": {k: t[k] for k in ("salu_wave_insts", "lds_wave_insts", "vmem_rd_wave_insts") if k in t}}
+    if "wave_quad_cycles" in t and "wait_any_quad_cycles" in t:
+        out["wave_time_in_s_waitcnt"] = round(t["wait_any_quad_cycles"] / t["wave_quad_cycles"], 4)
+    return out
 
 
 def cpu_baseline(scene, renderer, np):

@@ -83,7 +83,7 @@ namespace SoftwareRenderer
         public ulong Flushes;
     }
 
-    public enum SwrProgram { FlatColor = 0, Gouraud = 1, Dust2LambertFog = 2, Phong4Point = 3 }
+    public enum SwrProgram { FlatColor = 0, Gouraud = 1, Dust2LambertFog = 2, Phong4Point = 3, DebugVaryings = 4 }
 
     // ---------------------------------------------------------------- the 49 entry points ----
     // Shaders.VertexInput (Shaders.cs:10-24) IS swr_vertex: four sequential System.Numerics fields, 48 bytes, blittable.

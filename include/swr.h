@@ -61,7 +61,10 @@ enum {
     SWR_PROG_FLAT_COLOR = 0,        /* VS of Renderer.cs:830-846 with Interpolate=false; FS = input.Color */
     SWR_PROG_GOURAUD = 1,           /* same VS, Interpolate=true; FS = input.Color */
     SWR_PROG_DUST2_LAMBERT_FOG = 2, /* exactly Renderer.VertexShader/FragmentShader, Renderer.cs:830-860 */
-    SWR_PROG_PHONG_4POINT = 3       /* build-defined 4-point-light Phong (no reference semantics) */
+    SWR_PROG_PHONG_4POINT = 3,      /* build-defined 4-point-light Phong (no reference semantics) */
+    SWR_PROG_DEBUG_VARYINGS = 4     /* build-defined: FS returns the varyings of Shaders.VertexOutput that no other built-in reads, as
+                                     * Rasterizer.Interpolate delivers them -- (ScreenCoords.x + Normal.x, ScreenCoords.y + Normal.y,
+                                     * Barycentric.x + Normal.z, Barycentric.y + 0.5); Rasterizer.cs:390,598-613,638 */
 };
 
 /* Shaders.VertexInput, Shaders.cs:10-24 -- 48 bytes, identical memory layout */

@@ -469,12 +469,23 @@ static void fs_phong4(const oswr_uniforms* u, const oswr_vertex_output* in,
     out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2]; out[3] = base[3];
 }
 
+/* DEBUG_VARYINGS (build-defined program; its INPUTS are the reference's: Rasterizer.Interpolate's Normal :610-613, ScreenCoords
+ * :390,598-601 and Barycentric :638): rgba = (ScreenCoords.x + Normal.x, ScreenCoords.y + Normal.y, Barycentric.x + Normal.z,
+ * Barycentric.y + 0.5) */
+static void fs_debug_varyings(const oswr_vertex_output* in, float out[4]) {
+    out[0] = in->screen[0] + in->normal[0];
+    out[1] = in->screen[1] + in->normal[1];
+    out[2] = in->barycentric[0] + in->normal[2];
+    out[3] = in->barycentric[1] + 0.5f;
+}
+
 /* returns 1 when the delegate would return a value (built-ins always do) */
 int oswr_fragment_shader(int program, const oswr_uniforms* u, const oswr_vertex_output* in,
                          const uint8_t* tex, int tw, int th, float out[4]) {
     switch (program) {
     case OSWR_PROG_DUST2_LAMBERT_FOG: fs_dust2(u, in, tex, tw, th, out); return 1;
     case OSWR_PROG_PHONG_4POINT:      fs_phong4(u, in, tex, tw, th, out); return 1;
+    case OSWR_PROG_DEBUG_VARYINGS:    fs_debug_varyings(in, out); return 1;
     case OSWR_PROG_FLAT_COLOR:
     case OSWR_PROG_GOURAUD:
     default: memcpy(out, in->color, 16); return 1;

@@ -67,7 +67,8 @@ enum {
     OSWR_PROG_FLAT_COLOR = 0,        /* VS = Renderer.cs:830-846 with Interpolate=false; FS returns input.Color */
     OSWR_PROG_GOURAUD = 1,           /* same VS, Interpolate=true; FS returns input.Color */
     OSWR_PROG_DUST2_LAMBERT_FOG = 2, /* exactly Renderer.cs:830-860 */
-    OSWR_PROG_PHONG_4POINT = 3       /* build-defined (no reference semantics): see swr_oracle.c */
+    OSWR_PROG_PHONG_4POINT = 3,      /* build-defined (no reference semantics): see swr_oracle.c */
+    OSWR_PROG_DEBUG_VARYINGS = 4     /* build-defined: returns the varyings no other built-in reads -- Normal, ScreenCoords, Barycentric */
 };
 
 typedef struct {

@@ -114,6 +114,7 @@ struct swr_context {
     bool sync_flush = false;                  // SWR_SYNC_FLUSH=1: read the pair total back in every flush
     uint32_t debug_fill_capacity = 0;         // SWR_DEBUG_FILL_CAPACITY=n: k_bin<FILL> of optimistic flushes sees a list of n entries (tests)
 
+    DevBuf d_vnorm;          // VertexOutput.Normal per VOut entry: allocated and written only for batches with a DEBUG_VARYINGS draw
     DevBuf d_upload, d_vout, d_recs, d_slot_tb;   // d_upload = draws | vertex block map | triangle block map of the running batch
     FrameSlot slots[SWR_SLOTS];
     uint32_t slot_next = 0;
@@ -315,6 +316,10 @@ int sync_locked(swr_context* c) {
 }
 
 enum { MODE_SYNC = 0, MODE_ASYNC = 1 };
+static bool b_has_debug_varyings(const Batch& b) {
+    for (auto& d : b.draws) if (d.p.program == SWR_PROG_DEBUG_VARYINGS) return true;
+    return false;
+}
 const unsigned long long kMaxPairs = 1ull << 30;       // list entries per round (4 GiB of slot ids)
 
 size_t pair_capacity(const swr_context* c) {
@@ -473,6 +478,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.recs = c->d_recs.as<TriRec>();
         ra.vout = c->d_vout.as<VOut>();
         ra.vout_bytes = (uint32_t)std::min<size_t>(c->d_vout.cap, 0xfffffff0u);
+        ra.vnorm = b_has_debug_varyings(b) ? c->d_vnorm.as<float4>() : nullptr;
         ra.draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
         ra.tile_start = c->d_tile_start.as<uint32_t>();
         ra.tile_count = c->d_tile_count.as<uint32_t>();
@@ -497,7 +503,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
                 phong_default = phong_default && d.p.program == SWR_PROG_PHONG_4POINT &&
                                 d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
                 grows = grows && (d.p.depth_test == SWR_DEPTH_LESS || d.p.depth_test == SWR_DEPTH_LESSEQUAL);
-                phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
+                phong = phong || d.p.program == SWR_PROG_PHONG_4POINT || d.p.program == SWR_PROG_DEBUG_VARYINGS;   // (the generic PHONG kernels carry DEBUG_VARYINGS)
                 none = none || d.p.blend == SWR_BLEND_NONE;
                 // the reference's own frame: every mesh drawn with Renderer's shader pair and the RenderMesh defaults
                 dust2_default = dust2_default && d.p.program == SWR_PROG_DUST2_LAMBERT_FOG &&
@@ -568,6 +574,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const size_t up_bytes = off_vis + (any_cull ? nd * 4 : 0);
     if ((rc = ensure(c, c->d_upload, up_bytes))) return rc;
     if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
+    const bool dbgv = b_has_debug_varyings(b);
+    if (dbgv && (rc = ensure(c, c->d_vnorm, c->d_vout.cap / 4))) return rc;        // one float4 per VOut entry
     if ((rc = ensure(c, c->d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
     if ((rc = ensure(c, c->d_slot_tb, (size_t)(spt * T) * 8))) return rc;
     if ((rc = ensure(c, c->d_want, (size_t)(spt * T) + 64))) return rc;
@@ -615,7 +623,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         ScopedSpan sp(c, ST_VERTEX);
         hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
                            d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible,
-                           reinterpret_cast<float*>((char*)c->d_upload.p + offsetof(DrawParams, fog_r1)));
+                           reinterpret_cast<float*>((char*)c->d_upload.p + offsetof(DrawParams, fog_r1)),
+                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -624,7 +633,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            d_draws, d_tblocks, (const VOut*)c->d_vout.as<VOut>(),
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
-                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible);
+                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible,
+                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
         SWR_HIP(c, hipGetLastError());
     }
     rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode);
@@ -691,6 +701,13 @@ int flush_locked(swr_context* c) {
     memcpy(b.clear_rgba, c->clear_rgba, 16);
     b.near_clip = c->near_clip;
     b.wireframe = c->debug_mode == SWR_DEBUG_WIREFRAME;
+    if (b.wireframe && b_has_debug_varyings(b)) {
+        // DrawLine hands Interpolate the TRIANGLE's outputs[0..1] for all three edges (Rasterizer.cs:421-423); a line record keeps the
+        // edge's end points, not those two vertices' screen positions, so the program's ScreenCoords term is not available there
+        for (auto& d : b.draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+        c->pend_verts = c->pend_tris = 0;
+        return fail(c, SWR_ERR_UNSUPPORTED, "SWR_PROG_DEBUG_VARYINGS is not available in DebugMode.Wireframe");
+    }
     b.seq = c->next_seq++;
     b.color = c->color; b.depth = c->depth;
     c->pend_clear_color = c->pend_clear_depth = false;
@@ -775,8 +792,12 @@ static bool band_rejects(const swr_context* c, const swr_mesh* m, const float* m
 int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float* view, const float* proj,
                 int program, const swr_uniforms* u, const swr_texture* tex, int cull, int depth_test, int blend, bool frustum_cull = false) {
     if (!mesh || !model || !view || !proj) return fail(c, SWR_ERR_INVALID_ARG, "null argument to render_mesh");
-    if (program < SWR_PROG_FLAT_COLOR || program > SWR_PROG_PHONG_4POINT)
+    if (program < SWR_PROG_FLAT_COLOR || program > SWR_PROG_DEBUG_VARYINGS)
         return fail(c, SWR_ERR_INVALID_ARG, "unknown program id");
+#if SWR_VARY_GLOBAL == 0
+    if (program == SWR_PROG_DEBUG_VARYINGS)      // (an A/B build of tools/ablate.py: the program lives on the kernels that fetch varyings from HBM)
+        return fail(c, SWR_ERR_UNSUPPORTED, "SWR_PROG_DEBUG_VARYINGS needs a build with SWR_VARY_GLOBAL != 0");
+#endif
     if ((program == SWR_PROG_DUST2_LAMBERT_FOG || program == SWR_PROG_PHONG_4POINT) && !u)
         return fail(c, SWR_ERR_INVALID_ARG, "this program needs a uniform block");
     if (cull < 0 || cull > 2 || depth_test < 0 || depth_test > 7 || blend < 0 || blend > 3)
@@ -930,7 +951,7 @@ void swr_destroy(swr_context* c) {
         if (c->present_done[i]) (void)hipEventDestroy(c->present_done[i]);
         release(c->present_buf[i]);
     }
-    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_recs,
+    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_vnorm, &c->d_recs,
                        &c->d_slot_tb, &c->d_want, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);

@@ -22,7 +22,9 @@ struct BlockMap { uint32_t draw; uint32_t first; };
 __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ draws,
                                                 const BlockMap* __restrict__ blocks,
                                                 VOut* __restrict__ vout, const uint32_t* __restrict__ visible,
-                                                float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */) {
+                                                float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */,
+                                                float4* __restrict__ vnorm /* VertexOutput.Normal per VOut entry, or null: only batches
+                                                                              with a DEBUG_VARYINGS draw carry it (see VOut) */) {
     const BlockMap bm = blocks[blockIdx.x];
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
@@ -54,10 +56,11 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
     o[1] = q2;
     o[2] = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
     o[3] = make_float4(tn[2] / len, world[0], world[1], world[2]);
+    if (vnorm) vnorm[dp->vert_base + local] = make_float4(n[0], n[1], n[2], 0.0f);      // Normal = input.Normal, Renderer.cs:842
 }
 
 // a vertex moving through clip + setup: the stored varyings plus the Interpolate flag
-struct SVert { VOut v; bool interp; };
+struct SVert { VOut v; bool interp; float nrm[3]; /* VertexOutput.Normal: carried only when the batch stores it (vnorm) */ };
 
 __device__ __forceinline__ void svert_lerp(const SVert& a, const SVert& b, float t, SVert& r) {
     // Shaders.Lerp(a, b, t, interpolate: true), Shaders.cs:50-95 (the clipper always passes true)
@@ -71,6 +74,8 @@ __device__ __forceinline__ void svert_lerp(const SVert& a, const SVert& b, float
     for (int i = 0; i < 3; ++i) r.v.wn[i] = nm_lerp(a.v.wn[i], b.v.wn[i], t);      // no renormalisation, :72-73
 #pragma unroll
     for (int i = 0; i < 3; ++i) r.v.wpos[i] = nm_lerp(a.v.wpos[i], b.v.wpos[i], t);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) r.nrm[i] = nm_lerp(a.nrm[i], b.nrm[i], t);           // Vector3.Lerp(a.Normal, b.Normal, t), Shaders.cs:55
     r.interp = true;
 }
 
@@ -187,7 +192,8 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                FrameParams fp,
                                                Counters* __restrict__ counters /* 64 replicas */,
                                                const Ctrl* __restrict__ ctrl, int count_stats, int wireframe,
-                                               const uint32_t* __restrict__ visible) {
+                                               const uint32_t* __restrict__ visible,
+                                               float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */) {
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
@@ -228,6 +234,14 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                 load_vout(vout_ro + r0, v[0].v);
                 load_vout(vout_ro + r1, v[1].v);
                 load_vout(vout_ro + r2, v[2].v);
+                if (vnorm) {
+                    const float4 n0 = vnorm[r0], n1 = vnorm[r1], n2 = vnorm[r2];
+                    v[0].nrm[0] = n0.x; v[0].nrm[1] = n0.y; v[0].nrm[2] = n0.z;
+                    v[1].nrm[0] = n1.x; v[1].nrm[1] = n1.y; v[1].nrm[2] = n1.z;
+                    v[2].nrm[0] = n2.x; v[2].nrm[1] = n2.y; v[2].nrm[2] = n2.z;
+                } else {
+                    for (int i = 0; i < 3; ++i) v[i].nrm[0] = v[i].nrm[1] = v[i].nrm[2] = 0.0f;
+                }
                 // ClipTriangleAgainstNearPlane, Rasterizer.cs:95-160
                 SVert poly[4];
                 int n = 0;
@@ -256,6 +270,7 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                     VOut* pool = clip_pool + 4ull * gt;
                     const uint32_t pbase = clip_pool_base + 4u * gt;
                     for (int k = 0; k < n; ++k) store_vout(pool + k, poly[k].v);
+                    if (vnorm) for (int k = 0; k < n; ++k) vnorm[pbase + (uint32_t)k] = make_float4(poly[k].nrm[0], poly[k].nrm[1], poly[k].nrm[2], 0.0f);
                     // fan (0, k, k+1), Rasterizer.cs:154-157
                     n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), poly[0], poly[1], poly[2],
                                               pbase, pbase + 1, pbase + 2, recs + slot, &tbs[0], wireframe != 0);

@@ -17,6 +17,7 @@ struct RasterArgs {
     const DrawParams* __restrict__ draws;
     const uint32_t* __restrict__ tile_start;
     const uint32_t* __restrict__ tile_count;
+    const float4* __restrict__ vnorm;          // VertexOutput.Normal per VOut entry (DEBUG_VARYINGS batches only, else null)
     uint32_t vout_bytes;                       // size of the VOut array (< 4 GiB: k_raster_c addresses it with 32-bit byte offsets)
     const uint4* __restrict__ pair_refs;       // per pair {slot, vertex refs of outputs[0..2]} (k_cover)
     const uint32_t* __restrict__ tile_order;   // band-local tile indices, heaviest first (k_tile_place)
@@ -248,6 +249,25 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     }
     if (PHONG && program == SWR_PROG_PHONG_4POINT) return fs_phong4(dp, dc, f);
     return fs_dust2(dc, f);
+}
+
+// SWR_PROG_DEBUG_VARYINGS: Rasterizer.Interpolate for the varyings no other built-in program reads -- Normal (Rasterizer.cs:610-613),
+// ScreenCoords (:390, :598-601), Barycentric (:583-585, :638) -- and the build-defined program that returns them.  Plain IEEE
+// divisions (a debug program: no division cores).  na/nb/nc = the three outputs' Normal, s?x/s?y = their screen positions (TriRec).
+__device__ __forceinline__ float4 shade_debug_varyings(float w0f, float w1f, float w2f, float wa_clip, float wb_clip, float wc_clip,
+                                                       float4 na, float4 nb, float4 nc, const float sx[3], const float sy[3],
+                                                       float inv_width, float inv_height) {
+    const float ra = w0f / wa_clip, rb = w1f / wb_clip, rc = w2f / wc_clip;          // :576-578
+    const float inv_sum = (ra + rb) + rc;                                             // :579
+    const float w = 1.0f / inv_sum;                                                   // :582
+    const float wa = ra * w, wb = rb * w;                                             // :583-584
+#define SWR_PERSP_D(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
+    // outputs[i].ScreenCoords = (screenCoords[i].X * invWidth, screenCoords[i].Y * invHeight), :390
+    const float scx = SWR_PERSP_D(sx[0] * inv_width, sx[1] * inv_width, sx[2] * inv_width);
+    const float scy = SWR_PERSP_D(sy[0] * inv_height, sy[1] * inv_height, sy[2] * inv_height);
+    const float nx = SWR_PERSP_D(na.x, nb.x, nc.x), ny = SWR_PERSP_D(na.y, nb.y, nc.y), nz = SWR_PERSP_D(na.z, nb.z, nc.z);
+#undef SWR_PERSP_D
+    return make_float4(scx + nx, scy + ny, wa + nz, wb + 0.5f);
 }
 
 // ---- small utility kernels -------------------------------------------------------------------

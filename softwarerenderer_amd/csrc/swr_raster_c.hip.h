@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 //   staged in LDS (round 2's layout): nine rows per pair (twelve with the 4-light program's world position), 292 B per pair;
 //   from the vertex-stage output in HBM: buffer loads with staged byte offsets -- the lanes of one pair read the same 16-byte rows,
 //     a chunk touches the vertices of 3-4 pairs -- and only what the chain replay, the depth test and Interpolate's divisions need
-//     stays staged: 160 B per pair, 8,080 B per wave with 16 pairs = 18 waves per CU instead of 16 (LDS is allocated in units of
+//     stays staged: 176 B per pair, 8,336 B per wave with 16 pairs = 18 waves per CU instead of 16 (LDS is allocated in units of
 //     1,280 B, tools/ubench/lds_occupancy.hip).
 // Measured on cfg3 (profiles/r03_raster_experiments.md): the loads cost 7 % at equal occupancy and the two extra waves return 4-5 %,
 // so the kernels WITHOUT the 4-light program keep the staged layout; the kernels that carry it (PHONG = true: they had to shrink
@@ -377,6 +377,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 //   SWR_VARY_GLOBAL: 4: byte offsets of outputs[0..2] in the VOut array, clip.w of outputs[0]
 //                    5: refined reciprocals of the three clip.w (Interpolate's divisions, see div_core), clip.w of outputs[1]
 //                    (clip.w of outputs[2] rides in the row-start entry)
+//                    6: byte offset of the pair's TriRec (DEBUG_VARYINGS reads the three screen positions from it)
 //   else 4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the output's wn.z, y by the refined reciprocal of clip.w),
 //   color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
 #ifdef SWR_ABL_VARY_ALIAS
@@ -387,7 +388,7 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
     static constexpr bool VG = SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG);
-    static constexpr int NQ = VG ? 6 : (PHONG ? 16 : 13);
+    static constexpr int NQ = VG ? 7 : (PHONG ? 16 : 13);
     static constexpr int BATCH = (PHONG && !VG) ? SWR_BATCH_PHONG : SWR_BATCH;       // pairs staged per batch
     static constexpr int WINDOW = (PHONG && !VG) ? SWR_WINDOW_PHONG : SWR_WINDOW;    // candidate pairs examined per batch
     static constexpr int RT_ROWS = VG ? 8 : 4;     // a row-start entry every RT_ROWS rows of a pair
@@ -470,6 +471,25 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
     constexpr int RT_ROWS = WaveLdsC<PHONG>::RT_ROWS;
     // the VOut array as a raw buffer: one 32-bit byte offset per vertex in a VGPR, the 16-byte row as the instruction's immediate
     const __amdgpu_buffer_rsrc_t vout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.vout, 0, (int)a.vout_bytes, 0x00020000);
+    // SWR_PROG_DEBUG_VARYINGS (generic PHONG kernels only): Normal of the three outputs from the side array, screen positions from the TriRec
+    auto shade_debug = [&L, &a](int t, float w0f, float w1f, float w2f) {
+        if (!(PHONG && VG)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const __amdgpu_buffer_rsrc_t nrm_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.vnorm, 0, (int)(a.vout_bytes >> 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.recs, 0, 0x7ffffff0, 0x00020000);
+        const float4 q4 = L.stage[VG ? 4 : 0][t], q5 = L.stage[VG ? 5 : 0][t], q6 = L.stage[VG ? 6 : 0][t];
+        auto ld4 = [](__amdgpu_buffer_rsrc_t r, uint32_t off) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+            return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        };
+        const float4 na = ld4(nrm_rsrc, __float_as_uint(q4.x) >> 2), nb = ld4(nrm_rsrc, __float_as_uint(q4.y) >> 2), nc = ld4(nrm_rsrc, __float_as_uint(q4.z) >> 2);
+        const uint32_t ro = __float_as_uint(q6.x);
+        const float4 r0 = ld4(rec_rsrc, ro), r1 = ld4(rec_rsrc, ro + 16u);
+        const float sx[3] = { r0.x, r0.y, r0.z }, sy[3] = { r0.w, r1.x, r1.y };
+        float wc_clip = 0.0f;
+        if constexpr (VG) wc_clip = L.rowtab[0][t].w;
+        const float inv_w = 1.0f / (float)(a.fp.width - 1), inv_h = 1.0f / (float)(a.fp.height - 1);      // Rasterizer.cs:362-363
+        return shade_debug_varyings(w0f, w1f, w2f, q4.w, q5.w, wc_clip, na, nb, nc, sx, sy, inv_w, inv_h);
+    };
     // part: 0 = everything, 1 = only the three uv rows (SWR_VARY_EARLY 3: requested ahead of the chain replay, the texel address hangs
     // on them), 2 = everything but the uv rows, which `V` already holds
     auto load_varyings = [&L, vout_rsrc](int t, bool fastdiv, int part = 0, TriVaryings V = TriVaryings()) {
@@ -648,6 +668,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                 fastdiv = div_operands_safe3(wa, wb, wc);
                 L.stage[VG ? 4 : 0][ci] = make_float4(__uint_as_float(ref.y << 6), __uint_as_float(ref.z << 6), __uint_as_float(ref.w << 6), wa);
                 L.stage[VG ? 5 : 0][ci] = make_float4(rcp_refined(wa), rcp_refined(wb), rcp_refined(wc), wb);
+                L.stage[VG ? 6 : 0][ci] = make_float4(__uint_as_float(ref.x << 6), 0.0f, 0.0f, 0.0f);
                 wc_stage = wc;
             } else {
                 const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.vout + ref.y);
@@ -925,7 +946,8 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 #ifdef SWR_ABL_NOSHADE
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                        const float4 src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
+                        const float4 src = (PHONG && PROG < 0 && f_program == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
+                                           shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                                  (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
                                                                  (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
 #endif
@@ -940,7 +962,8 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     e_d = d;
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
-                        e_src = shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
+                        e_src = (PHONG && PROG < 0 && f_program == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
+                                shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                       (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
                                                       (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);

@@ -125,6 +125,10 @@ def gather_bands(local_band, height: int, width: int, rank: int, world_size: int
                 if work is not None:
                     work.wait()
                 assemble()
+            # the receive buffers were allocated on the calling stream and are read on `stream`: tell the caching allocator, or it
+            # may hand their memory to the next allocation of the render stream while the assembly copy is still pending
+            for b in bufs:
+                b.record_stream(stream)
         else:
             if async_op and work is not None:
                 work.wait()

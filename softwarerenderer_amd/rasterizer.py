@@ -61,6 +61,7 @@ class Program(enum.IntEnum):        # built-in programs (include/swr.h)
     Gouraud = 1
     Dust2LambertFog = 2
     Phong4Point = 3
+    DebugVaryings = 4               # build-defined: returns Normal / ScreenCoords / Barycentric (the varyings no other built-in reads)
 
 
 def _f32(a, n=None):
@@ -259,6 +260,10 @@ class Shaders:
     @staticmethod
     def Dust2LambertFog(uniforms=None, texture=None):     # Renderer.cs:830-860
         return ShaderProgram(Program.Dust2LambertFog, uniforms, texture)
+
+    @staticmethod
+    def DebugVaryings():
+        return ShaderProgram(Program.DebugVaryings)
 
     @staticmethod
     def Phong4Point(uniforms, texture=None):

@@ -150,7 +150,8 @@ def test_csharp_shim_keeps_the_reference_signature_and_enum_ordinals():
     assert sig, "RenderMesh must keep the signature and defaults of Rasterizer.cs:163-174"
     hdr = open(os.path.join(ROOT, "include", "swr.h")).read()
     for cs, c in (("FlatColor = 0", "SWR_PROG_FLAT_COLOR = 0"), ("Gouraud = 1", "SWR_PROG_GOURAUD = 1"),
-                  ("Dust2LambertFog = 2", "SWR_PROG_DUST2_LAMBERT_FOG = 2"), ("Phong4Point = 3", "SWR_PROG_PHONG_4POINT = 3")):
+                  ("Dust2LambertFog = 2", "SWR_PROG_DUST2_LAMBERT_FOG = 2"), ("Phong4Point = 3", "SWR_PROG_PHONG_4POINT = 3"),
+                  ("DebugVaryings = 4", "SWR_PROG_DEBUG_VARYINGS = 4")):
         assert cs in CS and c in hdr
     for fwd in ("SetPixel", "GetPixel", "ClearColorBuffer", "SetDepth", "GetDepth", "ClearDepthBuffer", "Resize", "Present"):
         assert re.search(r"public static \w+ %s\(" % fwd, CS), fwd          # MainWindow.cs:320-321,382-436 forwards

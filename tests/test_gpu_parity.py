@@ -312,3 +312,37 @@ def test_hand_derived_kat_scenes_on_the_gpu(device):
         r.close()
         assert tuple(c[px[1], px[0]]) == expect
         run_both(device, s)
+
+
+@pytest.mark.parametrize("make", [
+    lambda: scenes.cfg3(320, 256, (2, 2), (16, 12), tex_size=32, seed=71, program=Program.DebugVaryings),
+    lambda: scenes.near_clip_scene(program=Program.DebugVaryings),                 # the clipper's vertices: Normal lerped, ScreenCoords recomputed
+    lambda: scenes.state_scene(program=Program.DebugVaryings, blend=BlendMode.None_, seed=72),     # row early-out kernel
+], ids=["patches", "nearclip", "blend_none"])
+def test_debug_varyings_program_carries_normal_screencoords_barycentric(device, make):
+    """R2 complete: the varyings of Shaders.VertexOutput that no other built-in program reads -- Normal
+    (Rasterizer.cs:610-613), ScreenCoords (:390,598-601), Barycentric (:638) -- travel through the raster path and come out of the
+    build-defined program SWR_PROG_DEBUG_VARYINGS exactly as the oracle's Rasterizer.Interpolate delivers them."""
+    scene = make()
+    run_both(device, scene)
+    rc, _, _ = render_oracle(scene)
+    assert np.isfinite(rc).all() and float(np.abs(rc[..., :3]).max()) > 0.0
+
+
+def test_debug_varyings_in_wireframe_is_refused_not_wrong(device):
+    """DrawLine interpolates the TRIANGLE's outputs[0..1] on every edge (Rasterizer.cs:421-423); the backend's line records do not
+    keep those two vertices' screen positions, so the combination is refused (SWR_ERR_UNSUPPORTED) rather than rendered differently."""
+    from softwarerenderer_amd import _native
+    from softwarerenderer_amd.rasterizer import DebugMode, Rasterizer
+    scene = scenes.cfg3(128, 128, (1, 1), (6, 4), tex_size=16, seed=73, program=Program.DebugVaryings)
+    Rasterizer.RenderDebugMode = DebugMode.Wireframe
+    try:
+        r = scenes.SceneRenderer(device, scene)
+        with pytest.raises(_native.SwrError) as e:
+            r.render()
+        assert e.value.code == _native.SWR_ERR_UNSUPPORTED
+        r.close()
+    finally:
+        Rasterizer.RenderDebugMode = DebugMode.None_
+    device.sync()
+    run_both(device, scenes.cfg2(200, 120, 300, seed=74))          # the context is fine afterwards

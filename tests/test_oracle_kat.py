@@ -413,3 +413,36 @@ def test_wireframe_drawline_by_hand(oracle_lib):
     assert expect.sum() == 3 * 128 - 3
     assert np.array_equal(color[expect], np.tile(np.float32([0.5, 0.25, 1.0, 1.0]), (expect.sum(), 1)))
     assert np.array_equal(color[~expect], np.tile(np.float32([0, 0, 0, 1]), ((~expect).sum(), 1)))
+
+
+def test_debug_varyings_program_returns_the_interpolated_normal_screencoords_barycentric(oracle_lib):
+    """SWR_PROG_DEBUG_VARYINGS by hand: Interpolate at the centroid of a triangle whose three clip.w are 1 (weights -1/3 each after the
+    area division, i.e. (rA, rB, rC) = (-1/3, -1/3, -1/3), w = -1, Barycentric = (1/3, 1/3, 1/3)): Normal and ScreenCoords come out
+    as the plain averages, and the program returns (Screen.x + Normal.x, Screen.y + Normal.y, Bary.x + Normal.z, Bary.y + 0.5)."""
+    import ctypes as C
+    from oracle.binding import OVertexOutput
+    lib = oracle_lib
+    verts = (OVertexOutput * 3)()
+    normals = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)]
+    screens = [(0.0, 0.0), (0.75, 0.0), (0.0, 0.75)]
+    for i in range(3):
+        verts[i].clip[:] = (0.0, 0.0, 0.5, 1.0)
+        verts[i].normal[:] = normals[i]
+        verts[i].screen[:] = screens[i]
+        verts[i].interpolate = 1
+        verts[i].has_data = 0
+    out = OVertexOutput()
+    third = np.float32(-1.0) / np.float32(3.0)
+    lib.oswr_interpolate.restype = None
+    lib.oswr_interpolate(C.byref(verts[0]), C.byref(verts[1]), C.byref(verts[2]), C.c_float(third), C.c_float(third), C.c_float(third),
+                         1, C.byref(out))
+    bary = [float(x) for x in out.barycentric]
+    assert all(abs(b - 1.0 / 3.0) < 1e-6 for b in bary)
+    assert abs(out.screen[0] - 0.25) < 1e-6 and abs(out.screen[1] - 0.25) < 1e-6
+    assert all(abs(float(out.normal[i]) - 1.0 / 3.0) < 1e-6 for i in range(3))
+    rgba = (C.c_float * 4)()
+    lib.oswr_fragment_shader.restype = C.c_int
+    assert lib.oswr_fragment_shader(4, None, C.byref(out), None, 0, 0, rgba) == 1
+    want = (np.float32(out.screen[0]) + np.float32(out.normal[0]), np.float32(out.screen[1]) + np.float32(out.normal[1]),
+            np.float32(out.barycentric[0]) + np.float32(out.normal[2]), np.float32(out.barycentric[1]) + np.float32(0.5))
+    assert tuple(np.float32(x) for x in rgba) == want

@@ -3,7 +3,7 @@
 # -> profiles/OUT_* (kernel stats + summaries of cfg3 / cfg2 / cfg4 / cfg5, SQ counter table, bench line) and profiles/<round>_traffic.json
 TAG=${1:-r02}; OUT=${2:-r02_final}
 cd "$(dirname "$0")/.." || exit 1
-python3 tools/summarize_rocprof.py $OUT gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/prof_${TAG}_bench.json gpurun_out/srchash_$TAG.txt cfg3 || exit 1
+python3 tools/summarize_rocprof.py $OUT gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG gpurun_out/prof_${TAG}_bench.json gpurun_out/srchash_$TAG.txt cfg3 gpurun_out/pmc_sq1_$TAG || exit 1
 for c in cfg2 cfg4 cfg5; do
   python3 tools/summarize_rocprof.py ${OUT}_$c gpurun_out/prof_${TAG}_$c "" "" gpurun_out/bench_${TAG}_$c.json || exit 1
 done

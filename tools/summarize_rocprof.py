@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output dirs (gpurun_out/...) into a small tracked summary under profiles/.
 
-usage: summarize_rocprof.py TAG STATS_DIR [PMC_FETCH_DIR] [PMC_WRITE_DIR] [BENCH_JSON] [SRC_HASH_FILE CONFIG]
+usage: summarize_rocprof.py TAG STATS_DIR [PMC_FETCH_DIR] [PMC_WRITE_DIR] [BENCH_JSON] [SRC_HASH_FILE CONFIG [PMC_SQ_DIR]]
 Writes profiles/TAG_kernel_stats.csv (verbatim rocprofv3 --stats table) and profiles/TAG_summary.md; with SRC_HASH_FILE
 (bench.py --print-src-hash of the build that was profiled) also profiles/<round>_traffic.json, which bench.py reads for
 `roofline.traffic` -- and ignores when the kernel sources have changed since.
@@ -55,7 +55,16 @@ def main():
         txt = open(bench).read().strip().splitlines()
         js = [l for l in txt if l.startswith("{")]
         if js:
-            lines += ["", "bench.py line of the same command:", "", "```json", json.dumps(json.loads(js[-1]), indent=1), "```"]
+            line = json.loads(js[-1])
+            rk = [n for n in fetch if "k_raster_c" in n]
+            if rk and write and "roofline" in line and line["roofline"].get("traffic") is None:
+                # the line was printed before this script wrote the traffic file of the build: fill in what the PMC passes of the
+                # SAME call measured, so that the tracked summary never shows a stale or empty traffic field
+                f, w = fetch[rk[0]], write[rk[0]]
+                line["roofline"]["traffic"] = round((2.0 * f + w) * 1024 / 1e9, 4)
+                line["roofline"]["traffic_detail"] = {"file": "this profile round's PMC passes", "fetch_raw_gb": round(f * 1024 / 1e9, 4),
+                                                      "write_gb": round(w * 1024 / 1e9, 4), "raw_sum_gb": round((f + w) * 1024 / 1e9, 4)}
+            lines += ["", "bench.py line of the same command:", "", "```json", json.dumps(line, indent=1), "```"]
     open(os.path.join(prof, f"{tag}_summary.md"), "w").write("\n".join(lines) + "\n")
     if len(sys.argv) > 7 and fetch and write:
         src_hash = open(sys.argv[6]).read().strip()
@@ -70,6 +79,14 @@ def main():
                             "applies the guide's gfx950 correction (FETCH_SIZE x 2) and reports the raw figures beside it.")
         j["csrc_sha256"] = src_hash
         j[config] = {"kernel": k, "fetch_kib_raw": round(fetch[k], 1), "write_kib": round(write[k], 1)}
+        if len(sys.argv) > 8 and sys.argv[8]:
+            # instruction mix of the same kernel (SQ pass): what bench.py's roofline.valu_floor is computed from
+            for cn, key in (("SQ_INSTS_VALU", "valu_wave_insts"), ("SQ_INSTS_SALU", "salu_wave_insts"), ("SQ_INSTS_LDS", "lds_wave_insts"),
+                            ("SQ_INSTS_VMEM_RD", "vmem_rd_wave_insts"), ("SQ_WAVE_CYCLES", "wave_quad_cycles"),
+                            ("SQ_WAIT_INST_ANY", "wait_any_quad_cycles"), ("SQ_ACTIVE_INST_VALU", "valu_active_quad_cycles")):
+                m = pmc_means(sys.argv[8], cn)
+                if k in m:
+                    j[config][key] = round(m[k], 1)
         json.dump(j, open(tpath, "w"), indent=1)
     print("\n".join(lines[:20]))
 
