@@ -503,14 +503,18 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
                 phong_default = phong_default && d.p.program == SWR_PROG_PHONG_4POINT &&
                                 d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
                 grows = grows && (d.p.depth_test == SWR_DEPTH_LESS || d.p.depth_test == SWR_DEPTH_LESSEQUAL);
-                phong = phong || d.p.program == SWR_PROG_PHONG_4POINT || d.p.program == SWR_PROG_DEBUG_VARYINGS;   // (the generic PHONG kernels carry DEBUG_VARYINGS)
+                phong = phong || d.p.program == SWR_PROG_PHONG_4POINT;
                 none = none || d.p.blend == SWR_BLEND_NONE;
                 // the reference's own frame: every mesh drawn with Renderer's shader pair and the RenderMesh defaults
                 dust2_default = dust2_default && d.p.program == SWR_PROG_DUST2_LAMBERT_FOG &&
                                 d.p.blend == SWR_BLEND_ALPHA && d.p.depth_test == SWR_DEPTH_LESSEQUAL;
             }
             ra.depth_only_grows = grows ? 1 : 0;
-            if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);   // DrawLine has no early-out
+            if (b_has_debug_varyings(b)) {        // (never mixed with other programs, never wireframe: swr_render_mesh / flush_locked)
+                if (none) hipLaunchKernelGGL((k_raster_c<false, true, SWR_PROG_DEBUG_VARYINGS, -1, -1, true>), g, t, 0, c->stream, ra, mk, pc);
+                else hipLaunchKernelGGL((k_raster_c<false, true, SWR_PROG_DEBUG_VARYINGS>), g, t, 0, c->stream, ra, mk, pc);
+            }
+            else if (b.wireframe) hipLaunchKernelGGL((k_raster_c<true, true>), g, t, 0, c->stream, ra, mk, pc);   // DrawLine has no early-out
             else if (none) hipLaunchKernelGGL((k_raster_c<false, true, -1, -1, -1, true>), g, t, 0, c->stream, ra, mk, pc);
             else if (phong_default)
                 hipLaunchKernelGGL((k_raster_c<false, true, SWR_PROG_PHONG_4POINT, SWR_BLEND_ALPHA, SWR_DEPTH_LESSEQUAL>), g, t, 0, c->stream, ra, mk, pc);
@@ -809,6 +813,11 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     // keep a batch within the 32-bit slot / vertex numbering
     // (and the vertex-stage output -- one record per vertex plus four per triangle for the clipper -- below 4 GiB)
     if (c->pend_verts + (uint64_t)mesh->n_verts + 4 * (c->pend_tris + (uint64_t)n_tris) >= (1ull << 26)) {
+        int rc = flush_locked(c);
+        if (rc) return rc;
+    }
+    // SWR_PROG_DEBUG_VARYINGS has kernels of its own: a batch holds either only such draws or none (submission order is kept)
+    if (!c->draws.empty() && (c->draws.back().p.program == SWR_PROG_DEBUG_VARYINGS) != (program == SWR_PROG_DEBUG_VARYINGS)) {
         int rc = flush_locked(c);
         if (rc) return rc;
     }

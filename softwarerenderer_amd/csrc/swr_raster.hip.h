@@ -251,6 +251,75 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     return fs_dust2(dc, f);
 }
 
+// ---- Interpolate + Renderer.FragmentShader as ONE straight-line block: speculate, then verify ----------------------------------
+// shade_fragment() guards every shortcut where it is taken (division cores only for operands in range, the normal's renormalisation
+// only for a length in range, the texture wrap only where the index leaves the texture, ...): eight divergent regions, i.e. eight
+// times compare + exec save / restore + a skip branch that is TAKEN in the common case, and a scheduler that cannot move anything
+// across them.  For the reference's own frame -- DUST2 program, nearest texture bound, fog range and light direction finite (checked
+// per draw, on the scalar side) -- this version computes the common case unconditionally and only COLLECTS the conditions: `safe`
+// says whether every shortcut it took was legal for this lane.  The caller ballots `safe` over the chunk; if any shaded lane is
+// unsafe the whole chunk is shaded again by shade_fragment (exact, rare: degenerate weights, a texture coordinate exactly on the
+// wrap seam, a collapsed normal).  A result is used only after it has been verified, so the output is the reference's bit for bit;
+// and in the verified case NaNs are excluded, which makes Math.Clamp a v_med3 and MathF.Max a v_max.
+// (the uniforms stay in SGPRs: copies in vector registers -- v_mul with an SGPR operand issues at the slow rate in isolation -- were
+//  measured and bought nothing, profiles/r03_raster_experiments.md)
+__device__ __forceinline__ float4 shade_dust2_fast(const DrawConsts& u, const TriVaryings& V, float w0f, float w1f, float w2f, bool& safe) {
+    const float ra = div_core(w0f, V.a_w, V.a_r1), rb = div_core(w1f, V.b_w, V.b_r1), rc = div_core(w2f, V.c_w, V.c_r1);     // :576-578
+    const float inv_sum = (ra + rb) + rc;                                                                                      // :579
+    const float w = recip_core(inv_sum);                                                                                       // :582
+    // (conditions are combined with `&`: a short-circuit `&&` on lane values is a divergent region again)
+    bool ok = V.fastdiv & div_operands_safe3_arith(w0f, w1f, w2f) & (__builtin_fabsf(inv_sum) >= 0x1p-40f);
+#define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
+    const float tu = SWR_PERSP(V.a_uvn.x, V.b_uvn.x, V.c_uvn.x), tv = SWR_PERSP(V.a_uvn.y, V.b_uvn.y, V.c_uvn.y);
+    // Texture.Sample, Texture.cs:43-54; the wrap fix-ups are the verifier's business: an index outside the texture marks the lane unsafe
+    float fu = tu - (float)f2i(tu), fv = tv - (float)f2i(tv);
+    fu += (fu < 0) ? 1.0f : 0.0f;
+    fv += (fv < 0) ? 1.0f : 0.0f;
+    const int tx = f2i(fu * u.tex_wf), ty = f2i(fv * u.tex_hf);
+    ok = ok & ((uint32_t)tx < (uint32_t)u.tex_w) & ((uint32_t)ty < (uint32_t)u.tex_h);
+    // (an unsafe lane still loads: the index is clamped into the texture, its texel is never used)
+    const uint32_t ti = min((uint32_t)ty * (uint32_t)u.tex_w + (uint32_t)tx, (uint32_t)(u.tex_w * u.tex_h - 1));
+    typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+    const uint32_t texel = ((global_u32_ptr)(uintptr_t)u.tex)[ti];
+    __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
+    const float cr = SWR_PERSP(V.a_col.x, V.b_col.x, V.c_col.x), cg = SWR_PERSP(V.a_col.y, V.b_col.y, V.c_col.y),
+                cb = SWR_PERSP(V.a_col.z, V.b_col.z, V.c_col.z), ca = SWR_PERSP(V.a_col.w, V.b_col.w, V.c_col.w);
+    const float clip_z = SWR_PERSP(V.a_cz, V.b_cz, V.c_cz);
+#undef SWR_PERSP
+    const float wa = ra * w, wb = rb * w, wc = rc * w;                                                                         // :583-585
+    float n0 = (V.a_uvn.z * wa + V.b_uvn.z * wb) + V.c_uvn.z * wc;                                                             // :680-688
+    float n1 = (V.a_uvn.w * wa + V.b_uvn.w * wb) + V.c_uvn.w * wc;
+    float n2 = (V.a_wnz * wa + V.b_wnz * wb) + V.c_wnz * wc;
+    const float len_sq = dot3(n0, n1, n2, n0, n1, n2);
+    ok = ok & (len_sq > 1e-6f) & (len_sq <= 1.0e12f);
+    const float sc = recip_core(sqrt_core(len_sq));
+    n0 = n0 * sc; n1 = n1 * sc; n2 = n2 * sc;
+    // Renderer.FragmentShader, Renderer.cs:848-860.  The normal is finite here (verified length) and the light direction is finite
+    // (per-draw check), so the dot product is no NaN and MathF.Max is the plain maximum
+    const float diffuse = __builtin_fmaxf(0.25f, dot3(n0, n1, n2, -u.light_direction[0], -u.light_direction[1], -u.light_direction[2]));
+    const float fog_num = u.fog_end - clip_z;
+    ok = ok & div_operand_safe(fog_num);
+    const float fog_q = div_core(fog_num, u.fog_den, u.fog_r1);
+    float fog = __builtin_amdgcn_fmed3f(fog_q, 0.0f, 1.0f);        // Math.Clamp of a verified-finite quotient
+    fog = (fog * fog) * (3.0f - 2.0f * fog);
+    const float sl = 0.1f + 0.9f * diffuse;
+    const float4 tc = texture_unpack(texel);
+    const float br = cr * tc.x, bg = cg * tc.y, bb = cb * tc.z, ba = ca * tc.w;
+    float4 o;
+    o.x = nm_lerp(u.fog_color[0], (br * sl) * u.light_color[0], fog);
+    o.y = nm_lerp(u.fog_color[1], (bg * sl) * u.light_color[1], fog);
+    o.z = nm_lerp(u.fog_color[2], (bb * sl) * u.light_color[2], fog);
+    o.w = ba;
+    safe = ok;
+    return o;
+}
+// the per-draw half of the verification (wave-uniform, evaluated when the chunk's draw changes)
+__device__ __forceinline__ bool dust2_fast_applies(const DrawConsts& u) {
+    const float lx = u.light_direction[0], ly = u.light_direction[1], lz = u.light_direction[2];
+    const bool finite_l = (lx - lx) == 0.0f && (ly - ly) == 0.0f && (lz - lz) == 0.0f;       // no NaN, no infinity
+    return u.tex != nullptr && u.tex_h > 0 && u.tex_w > 0 && u.fog_r1 != 0.0f && finite_l;
+}
+
 // SWR_PROG_DEBUG_VARYINGS: Rasterizer.Interpolate for the varyings no other built-in program reads -- Normal (Rasterizer.cs:610-613),
 // ScreenCoords (:390, :598-601), Barycentric (:583-585, :638) -- and the build-defined program that returns them.  Plain IEEE
 // divisions (a debug program: no division cores).  na/nb/nc = the three outputs' Normal, s?x/s?y = their screen positions (TriRec).

@@ -370,6 +370,10 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_VARY_EARLY
 #define SWR_VARY_EARLY 3
 #endif
+// the DUST2 kernel shades with the straight-line speculate-then-verify shader (shade_dust2_fast, swr_raster.hip.h); 0 = always shade_fragment
+#ifndef SWR_FAST_SHADE
+#define SWR_FAST_SHADE 1
+#endif
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
@@ -410,12 +414,21 @@ struct __attribute__((aligned(16))) WaveLdsC {
 #ifdef SWR_ABL_LDSBYTES             // tools/ablate.py occupancy probe: dead LDS that lowers the waves per SIMD, nothing else changes
     uint32_t abl_pad[SWR_ABL_LDSBYTES / 4];
 #endif
-    struct RowStart3 { float x, y, z; };
-    typedef typename std::conditional<VG, float4, RowStart3>::type RowStart;     // (the staged-varyings layout has no room for a fourth word)
-    RowStart rowtab[RT_N][BATCH];    // [q][pair]: the pair's edge values at the start of its rows RT_ROWS (q + 1), i.e. the reference's
-                                     // row chain (Rasterizer.cs:532-534) run once per pair at staging: a fragment's row replay is then
-                                     // at most RT_ROWS - 1 add steps from the nearest entry instead of up to 15
-                                     // (.w: unused; with SWR_VARY_GLOBAL entry 0 carries clip.w of outputs[2])
+    // row-start table: the pair's edge values at the start of its rows RT_ROWS (q + 1), q = 0 .. RT_N - 1, i.e. the reference's row chain
+    // (Rasterizer.cs:532-534) run once per pair at staging: a fragment's row replay is then at most RT_ROWS - 1 add steps from the
+    // nearest entry instead of up to 15.  Staged-varyings layout: three planes of floats (address = plane + 4 t: no multiply);
+    // VG layout: one float4 per pair whose .w carries clip.w of outputs[2].
+    float rowtab3[VG ? 1 : RT_N][3][VG ? 1 : BATCH];
+    float4 rowtab4[VG ? RT_N : 1][VG ? BATCH : 1];
+    __device__ __forceinline__ void rt_store(int q, int t, float x, float y, float z, float w) {
+        if constexpr (VG) rowtab4[q][t] = make_float4(x, y, z, w);
+        else { rowtab3[q][0][t] = x; rowtab3[q][1][t] = y; rowtab3[q][2][t] = z; }
+    }
+    __device__ __forceinline__ void rt_load(int q, int t, float& x, float& y, float& z) const {
+        if constexpr (VG) { const float4 e = rowtab4[q][t]; x = e.x; y = e.y; z = e.z; }
+        else { x = rowtab3[q][0][t]; y = rowtab3[q][1][t]; z = rowtab3[q][2][t]; }
+    }
+    __device__ __forceinline__ float rt_w(int t) const { return rowtab4[0][VG ? t : 0].w; }
 };
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
@@ -471,9 +484,10 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
     constexpr int RT_ROWS = WaveLdsC<PHONG>::RT_ROWS;
     // the VOut array as a raw buffer: one 32-bit byte offset per vertex in a VGPR, the 16-byte row as the instruction's immediate
     const __amdgpu_buffer_rsrc_t vout_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.vout, 0, (int)a.vout_bytes, 0x00020000);
-    // SWR_PROG_DEBUG_VARYINGS (generic PHONG kernels only): Normal of the three outputs from the side array, screen positions from the TriRec
+    // SWR_PROG_DEBUG_VARYINGS (its own instantiations, PROG = 4: a batch holds either only such draws or none, swr_render_mesh flushes
+    // in between): Normal of the three outputs from the side array, screen positions from the TriRec
     auto shade_debug = [&L, &a](int t, float w0f, float w1f, float w2f) {
-        if (!(PHONG && VG)) return make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(PHONG && VG && PROG == SWR_PROG_DEBUG_VARYINGS)) return make_float4(0.f, 0.f, 0.f, 0.f);
         const __amdgpu_buffer_rsrc_t nrm_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.vnorm, 0, (int)(a.vout_bytes >> 2), 0x00020000);
         const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.recs, 0, 0x7ffffff0, 0x00020000);
         const float4 q4 = L.stage[VG ? 4 : 0][t], q5 = L.stage[VG ? 5 : 0][t], q6 = L.stage[VG ? 6 : 0][t];
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
         const float4 r0 = ld4(rec_rsrc, ro), r1 = ld4(rec_rsrc, ro + 16u);
         const float sx[3] = { r0.x, r0.y, r0.z }, sy[3] = { r0.w, r1.x, r1.y };
         float wc_clip = 0.0f;
-        if constexpr (VG) wc_clip = L.rowtab[0][t].w;
+        if constexpr (VG) wc_clip = L.rt_w(t);
         const float inv_w = 1.0f / (float)(a.fp.width - 1), inv_h = 1.0f / (float)(a.fp.height - 1);      // Rasterizer.cs:362-363
         return shade_debug_varyings(w0f, w1f, w2f, q4.w, q5.w, wc_clip, na, nb, nc, sx, sy, inv_w, inv_h);
     };
@@ -518,7 +532,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
             // the divisions' operands come from LDS (staged once per pair): they do not wait for the rows above
             V.a_r1 = q5.x; V.b_r1 = q5.y; V.c_r1 = q5.z;
             V.a_w = q4.w; V.b_w = q5.w;
-            if constexpr (VG) V.c_w = L.rowtab[0][t].w;
+            if constexpr (VG) V.c_w = L.rt_w(t);
             V.fastdiv = fastdiv;
             return V;
         }
@@ -589,6 +603,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
     DrawConsts dc = {};                    // per-draw constants of draw `dc_draw` (see DrawConsts)
     uint32_t dc_draw = 0xffffffffu;
     uint32_t batch_no = 0;
+    bool fast_draw = false;                // SWR_FAST_SHADE: the chunk's draw satisfies the per-draw conditions of shade_dust2_fast
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first BATCH survivors
         //      of the window are staged in LDS ----
@@ -716,10 +731,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                 for (int q = 0; q < WaveLdsC<PHONG>::RT_N; ++q) {
 #pragma unroll
                     for (int i = 0; i < RT_ROWS; ++i) { rw0 += b12; rw1 += b20; rw2 += b01; }            // :532-534
-                    typename WaveLdsC<PHONG>::RowStart e;
-                    e.x = rw0; e.y = rw1; e.z = rw2;
-                    if constexpr (VG) e.w = wc_stage;
-                    L.rowtab[q][ci] = e;
+                    L.rt_store(q, ci, rw0, rw1, rw2, wc_stage);
                 }
             }
             *reinterpret_cast<uint4*>(&L.mask[ci][0]) = m0;
@@ -824,12 +836,11 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
             // left it and no two lanes that survive the cut share a pixel, so reading before the cut changes nothing.
             const uint32_t fs_early = __float_as_uint(f2.w);
             const int nrow_e = (pix >> 4) - (int)(fs_early >> 8);          // (lines, invalid lanes: any value; q stays in 0..3)
-            const int q_e = nrow_e / RT_ROWS, qi_e = max(q_e, 1) - 1;
+            const int q_e = nrow_e >> (RT_ROWS == 8 ? 3 : 2), qi_e = max(q_e, 1) - 1;
             // (not in the row-early-out kernels: they are at the register limit, and three spilled dwords cost more than the round trip)
             float t0r_e = 0.0f, t1r_e = 0.0f, t2r_e = 0.0f, z_old = 0.0f;
             if (!EARLYOUT) {
-                const auto rt = L.rowtab[qi_e][t];
-                t0r_e = rt.x; t1r_e = rt.y; t2r_e = rt.z;
+                L.rt_load(qi_e, t, t0r_e, t1r_e, t2r_e);
                 z_old = L.z[pix];
             }
             // duplicate election: of the lanes that share a pixel in this chunk all but one must wait.  Which of them
@@ -889,7 +900,12 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 #endif
 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
-            if (draw0 != dc_draw) { dc_draw = draw0; dc = load_draw_consts(cdp); }       // wave-uniform: the constants live in SGPRs across chunks
+            if (draw0 != dc_draw) {                                                       // wave-uniform: the constants live in SGPRs across chunks
+                dc_draw = draw0; dc = load_draw_consts(cdp);
+#if SWR_FAST_SHADE
+                if (!PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG) fast_draw = dust2_fast_applies(dc);
+#endif
+            }
             const int f_program = PROG >= 0 ? PROG : dc.program, f_blend = BLEND >= 0 ? BLEND : dc.blend, f_dt = DT >= 0 ? DT : dc.depth_test;
             // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
             const bool f_interp = PROG > SWR_PROG_FLAT_COLOR ? true : (__float_as_uint(f1.w) & SWR_FLAG_INTERP) != 0u;
@@ -924,8 +940,8 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 #endif
                     // rows: from the nearest staged row start (rowtab: rows 4, 8, 12 of the pair), at most 3 steps
                     {
-                        const int q = nrow / RT_ROWS;
-                        if (EARLYOUT) { const auto rt = L.rowtab[qi_e][t]; t0r_e = rt.x; t1r_e = rt.y; t2r_e = rt.z; }
+                        const int q = nrow >> (RT_ROWS == 8 ? 3 : 2);
+                        if (EARLYOUT) L.rt_load(qi_e, t, t0r_e, t1r_e, t2r_e);
                         if (q > 0) { w0 = t0r_e; w1 = t1r_e; w2 = t2r_e; }          // (read ahead of the election, see there)
                         const int rem = nrow & (RT_ROWS - 1);
                         for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
@@ -946,10 +962,20 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 #ifdef SWR_ABL_NOSHADE
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
-                        const float4 src = (PHONG && PROG < 0 && f_program == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
-                                           shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
-                                                                 (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
-                                                                 (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);   // :507-509 / :321-323
+                        float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
+                        constexpr bool FAST = SWR_FAST_SHADE && !PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG;
+                        const TriVaryings Vs = (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
+                                               (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u);
+                        bool need_exact = !(FAST && fast_draw);           // wave-uniform
+                        if (FAST && fast_draw) {
+                            // speculate: the straight-line shader; verify: every shaded lane of the chunk took only legal shortcuts
+                            bool safe;
+                            src = shade_dust2_fast(dc, Vs, w0f, w1f, w2f, safe);
+                            need_exact = SWR_BALLOT(!safe) != 0ull;
+                        }
+                        if (need_exact)
+                            src = (PHONG && PROG == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
+                                  shade_fragment<PHONG>(cdp, dc, f_program, f_interp, Vs, w0f, w1f, w2f);                           // :507-509 / :321-323
 #endif
                         // triangles: W > 0 (:511); lines: W != 0 (:325)
                         if (is_line ? (src.w != 0.0f) : (src.w > 0.0f)) {
@@ -962,7 +988,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     e_d = d;
                     e_pass = depth_func(f_dt, d, L.z[pix]);
                     if (e_pass) {
-                        e_src = (PHONG && PROG < 0 && f_program == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
+                        e_src = (PHONG && PROG == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
                                 shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
                                                       (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
                                                       (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
