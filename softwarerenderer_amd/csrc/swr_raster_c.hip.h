@@ -259,8 +259,14 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
                     float w0 = w0r, w1 = w1r, w2 = w2r;
                     uint32_t acc = 0;                      // pixel startX + i ends at bit wsteps - 1 - i
                     for (int i = 0; i < wsteps; ++i) {
-                        const bool inside = fminf(fminf(w0, w1), w2) >= 0.0f || fmaxf(fmaxf(w0, w1), w2) <= 0.0f;   // :493-494
-                        acc = (acc << 1) | (inside ? 1u : 0u);
+                        // inside = all >= 0 || all <= 0 (:493-494) as lane masks (a ballot of ONE compare is the compare's own mask), then
+                        // acc = 2 acc + inside as ONE instruction: an add with that mask as carry-in (the compiler's own form is
+                        // v_cndmask 0/1 + v_lshl_or: two of the nine vector instructions of this loop)
+                        {
+                            const unsigned long long in_mask = SWR_BALLOT(fminf(fminf(w0, w1), w2) >= 0.0f) | SWR_BALLOT(fmaxf(fmaxf(w0, w1), w2) <= 0.0f);
+                            unsigned long long carry_out;
+                            asm("v_addc_co_u32 %0, %1, %2, %2, %3" : "=v"(acc), "=s"(carry_out) : "v"(acc), "s"(in_mask));
+                        }
                         w0 += a12; w1 += a20; w2 += a01;                                                  // :527-529
                     }
                     const uint32_t rowbits = ((__brev(acc) >> (32 - wsteps)) & colmask) << sh;
