@@ -3,7 +3,7 @@
 // A context records draws (Rasterizer.RenderMesh calls, Rasterizer.cs:163-174) in submission order
 // and executes them as ONE batch per flush:
 //     [k_frustum_cull ->] k_vertex -> k_setup -> k_bin<count> -> k_scan_sums/apply -> k_bin<fill> -> k_sort_tiles
-//     -> k_cover -> k_tile_hist/place -> k_raster_c
+//     (+ the tile order in its last blocks) -> k_cover -> k_raster_c
 // There is no CPU fallback anywhere in this file: every pixel is produced by the HIP kernels.
 #include <hip/hip_runtime.h>
 
@@ -122,7 +122,7 @@ struct swr_context {
     uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
     DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     DevBuf d_want;           // 1 byte per slot: COUNT's pair_may_cover decisions, replayed by FILL
-    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32: heaviest-first raster order
+    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32, [tile_bucket n_tiles] u8: heaviest-first raster order
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
@@ -374,7 +374,8 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     return ba;
 }
 
-int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode) {
+// counts_clear: the per-tile counters are already zero (k_setup of this batch cleared them)
+int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode, bool counts_clear = false) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
@@ -383,6 +384,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     uint32_t* tile_work = c->d_order.as<uint32_t>();
     uint32_t* tile_order = tile_work + n_tiles;
     uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
+    uint8_t* tile_bucket = reinterpret_cast<uint8_t*>(order_hist + 2 * SWR_ORDER_BUCKETS);     // [n_tiles]
     BinArgs ba = make_bin_args(c, b, lo, hi);
     ba.replayable = mode == MODE_ASYNC ? 1u : 0u;
     const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;          // = triangles
@@ -391,17 +393,17 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     const uint32_t bin_blocks = (bin_threads + 4u * ba.tpw - 1u) / (4u * ba.tpw);
     {
         ScopedSpan sp(c, ST_BIN);
-        SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
+        if (!counts_clear) SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
         hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
         const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
         unsigned long long* sums = d_total + 32;      // room for 1024 block sums
-        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums, order_hist);
         // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
         const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
         hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, ba.tile_count,
                            c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
                            cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
-                           mode == MODE_ASYNC ? 1 : 0, tile_work, order_hist);
+                           mode == MODE_ASYNC ? 1 : 0, (const uint32_t*)tile_work, order_hist, tile_bucket);
         SWR_HIP(c, hipGetLastError());
     }
     uint32_t cover_items = ba.list_capacity;          // async: grid covers the whole capacity, lanes beyond the total exit
@@ -432,7 +434,11 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         BinArgs bf = ba;
         // test hook: a FILL capacity below what COUNT was checked against forces the list-overflow path (bin_overflow)
         if (mode == MODE_ASYNC && c->debug_fill_capacity) bf.list_capacity = std::min(bf.list_capacity, c->debug_fill_capacity);
-        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks), dim3(256), 0, c->stream, bf);       // cursors were zeroed by k_scan_apply
+        // the grid's last blocks place the tiles in the raster kernel's dispatch order (tile_place_block)
+        bf.bin_blocks = bin_blocks;
+        bf.order_tiles_y = c->band_tile_rows;
+        bf.tile_bucket = tile_bucket; bf.order_hist = order_hist; bf.order_cursor = order_hist + SWR_ORDER_BUCKETS; bf.tile_order = tile_order;
+        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks + order_blocks(c->tiles_x, c->band_tile_rows)), dim3(256), 0, c->stream, bf);   // cursors were zeroed by k_scan_apply
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -451,23 +457,13 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.info = c->d_pcounts.as<uint2>();
         ca.refs = c->d_pair_refs.as<uint4>();
         ca.n_pairs = d_total;
-        ca.tile_work = tile_work;
         ca.ctrl = ctrl;
         ca.fp = frame_params(c);
         ca.fp.near_clip = b.near_clip;
-        if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
-        else hipLaunchKernelGGL(k_cover<false>, dim3((unsigned)((cover_items + 255u) / 256u)), dim3(256), 0, c->stream, ca);
-        SWR_HIP(c, hipGetLastError());
-    }
-    {
-        ScopedSpan sp(c, ST_SORT);
-        const int band_tiles_y = c->band_tile_rows;
-        const unsigned ob = (unsigned)(((c->tiles_x + 15) / 16) * ((band_tiles_y + 15) / 16));
-        hipLaunchKernelGGL(k_tile_hist, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
-                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), c->tiles_x, band_tiles_y, order_hist, ctrl);
-        hipLaunchKernelGGL(k_tile_place, dim3(ob), dim3(256), 0, c->stream, (const uint32_t*)tile_work,
-                           (const uint32_t*)c->d_tile_count.as<uint32_t>(), c->tiles_x, band_tiles_y, (const uint32_t*)order_hist,
-                           order_hist + SWR_ORDER_BUCKETS, tile_order, ctrl);
+        ca.dbg = d_total + 8;
+        const dim3 cg((unsigned)((cover_items + (uint32_t)SWR_COVER_BLOCK - 1u) / (uint32_t)SWR_COVER_BLOCK)), cb(SWR_COVER_BLOCK);
+        if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, cg, cb, 0, c->stream, ca);
+        else hipLaunchKernelGGL(k_cover<false>, cg, cb, 0, c->stream, ca);
         SWR_HIP(c, hipGetLastError());
     }
     {
@@ -489,6 +485,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.clear_color_on = cc ? 1 : 0;
         ra.clear_depth_on = cd ? 1 : 0;
         ra.tile_order = tile_order;
+        ra.tile_work = tile_work;
         ra.n_tiles = n_tiles;
         ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
         ra.ctrl = ctrl;
@@ -585,7 +582,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if ((rc = ensure(c, c->d_want, (size_t)(spt * T) + 64))) return rc;
     if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 8 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
+    if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 9 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
         // another tile count (resize / band change): the fragment counters gathered so far move into the carry words of d_total
         // (swr_get_stats adds them), in stream order, so totals survive a change of geometry
@@ -596,6 +593,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         }
         if ((rc = ensure(c, c->d_tile_stats, (size_t)n_tiles * 12))) return rc;
         SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
+        SWR_HIP(c, hipMemsetAsync(c->d_order.p, 0, (size_t)n_tiles * 4, c->stream));      // no fragment history for the new tiling
         c->tile_stats_tiles = n_tiles;
     }
     char* stage = (char*)slot_acquire(c, up_bytes);
@@ -638,10 +636,11 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
                            (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible,
-                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
+                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr,
+                           c->d_tile_count.as<uint32_t>(), n_tiles);
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode);
+    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode, !tblocks.empty());
     slot_submit(c);
     if (rc) return rc;
     if (cc || cd) return run_clear(c, b, cc, cd, b.clear_rgba);   // nothing was binned

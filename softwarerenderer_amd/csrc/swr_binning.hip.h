@@ -8,8 +8,10 @@
 //   k_scan        : exclusive scan -> tile_start, total pairs
 //   k_bin<FILL>   : list[tile_start + atomic cursor] = slot       (arbitrary order inside a tile)
 //   k_sort_tiles  : one wave per tile sorts its segment ascending (restores submission order)
-// plus, after k_cover has counted the fragments of every tile:
-//   k_tile_hist / k_tile_place : counting sort of the tiles by descending work -> the raster kernel's dispatch order
+// plus the raster kernel's dispatch order (tiles by descending work, a counting sort) without launches of its own: the weight of a
+// tile is its pair count of THIS flush + the fragments the raster kernel counted in it in the PREVIOUS flush (any permutation is
+// correct; a frame resembles the one before), so k_scan_apply -- which holds the counts -- builds the histogram and the last blocks
+// of k_bin<FILL>'s grid place the tiles (tile_place_block).
 #pragma once
 #include "swr_device.h"
 
@@ -39,6 +41,13 @@ struct BinArgs {
     uint8_t* __restrict__ want;          // per slot: which of its (<= 8) tiles passed pair_may_cover -- written by COUNT, read by FILL
     uint32_t tpw;                        // triangles per wave: 64, or fewer for small batches (a wave works through its big
                                          // triangles one after the other: with few triangles more, emptier waves finish sooner)
+    // FILL only: blocks [bin_blocks, gridDim.x) place the tiles in the raster kernel's dispatch order (tile_place_block)
+    uint32_t bin_blocks;
+    int order_tiles_y;                   // tile rows of the band
+    const uint8_t* __restrict__ tile_bucket;    // k_scan_apply: order_bucket of every tile
+    const uint32_t* __restrict__ order_hist;    // tiles per bucket
+    uint32_t* __restrict__ order_cursor;        // per bucket: tiles placed so far
+    uint32_t* __restrict__ tile_order;
 };
 
 // Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
@@ -100,6 +109,68 @@ __device__ __forceinline__ void bin_overflow(const BinArgs& a) {
         __hip_atomic_store(&a.ctrl->poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.ctrl->host_flag) __hip_atomic_store(a.ctrl->host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// ---- heaviest-first tile order for the raster kernel ---------------------------------------------
+// One wave rasterises one tile and tiles differ a lot in work, so the launch ends with a few long tiles running on
+// an otherwise idle chip.  Workgroups are dispatched in index order as slots free up: handing out the tiles by
+// descending work makes that dispatch a longest-first schedule.  Weight of a tile = the fragments k_raster_c counted in it
+// in the previous flush (RasterArgs::tile_work) + a per-pair cost on this flush's pair count: both are known when the scan
+// runs, so the order costs no launch (round 2: k_cover summed this flush's fragments per tile, then k_tile_hist and
+// k_tile_place ran between k_cover and the raster kernel: 11 us of launches + k_cover's tail).  With pair counts alone cfg2's
+// raster kernel is 10 % slower, cfg3's the same (profiles/r03_raster_experiments.md, section 9).
+// Counting sort over 8 buckets per octave; the order inside a bucket is arbitrary (tiles are independent).
+__device__ __forceinline__ uint32_t order_bucket(uint32_t w) {
+    if (w == 0u) return 0u;
+    const int e = 31 - __clz((int)w);
+    const uint32_t m = e >= 3 ? ((w >> (e - 3)) & 7u) : ((w << (3 - e)) & 7u);
+    return min((uint32_t)(e * 8) + m + 1u, (uint32_t)SWR_ORDER_BUCKETS - 1u);
+}
+#ifdef SWR_ORDER_BY_PAIRS          // A/B: no fragment history
+__device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return 16u * pairs; }
+#else
+__device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return frags + 16u * pairs; }
+#endif
+
+// Thread i of an ordering block -> tile: a block takes a 16x16-tile region, a wave an 8x8 quarter of it, so that
+// tiles which end up next to each other in the order (same block, same bucket, consecutive LDS ranks) are neighbours
+// on screen: the raster kernel hands runs of 64 consecutive entries to one XCD, whose L2 then serves the triangle
+// records and vertices that neighbouring tiles share.  Returns 0xffffffff outside the band.
+__device__ __forceinline__ uint32_t order_tile_of_thread(uint32_t block, int tiles_x, int tiles_y) {
+    const int sbx = (tiles_x + 15) >> 4;
+    const int bx = (int)(block % (uint32_t)sbx), by = (int)(block / (uint32_t)sbx);
+    const int t = threadIdx.x, q = t >> 6, w = t & 63;
+    const int tx = bx * 16 + (q & 1) * 8 + (w & 7), ty = by * 16 + (q >> 1) * 8 + (w >> 3);
+    return (tx < tiles_x && ty < tiles_y) ? (uint32_t)(ty * tiles_x + tx) : 0xffffffffu;
+}
+__host__ __device__ inline uint32_t order_blocks(int tiles_x, int tiles_y) { return (uint32_t)(((tiles_x + 15) / 16) * ((tiles_y + 15) / 16)); }
+
+// One 256-thread block of the placement (the blocks behind k_bin<FILL>'s own): every tile of its 16x16 region gets its position in
+// the order = tiles in heavier buckets + tiles of its bucket placed so far.  s_suf / s_cnt: SWR_ORDER_BUCKETS words of LDS each.
+__device__ __forceinline__ void tile_place_block(const BinArgs& a, uint32_t block, uint32_t* s_suf, uint32_t* s_cnt) {
+    const uint32_t t = threadIdx.x;
+    s_suf[t] = a.order_hist[t];
+    s_cnt[t] = 0u;
+    __syncthreads();
+    for (uint32_t off = 1; off < (uint32_t)SWR_ORDER_BUCKETS; off <<= 1) {       // inclusive suffix sum: tiles in this and heavier buckets
+        const uint32_t v = t + off < (uint32_t)SWR_ORDER_BUCKETS ? s_suf[t + off] : 0u;
+        __syncthreads();
+        s_suf[t] += v;
+        __syncthreads();
+    }
+    const uint32_t i = order_tile_of_thread(block, a.tiles_x, a.order_tiles_y);
+    uint32_t b = 0, rank = 0;
+    if (i != 0xffffffffu) {
+        b = a.tile_bucket[i];
+        rank = atomicAdd(&s_cnt[b], 1u);
+    }
+    __syncthreads();
+    // one global reservation per (block, bucket): same-address atomics with a return value are slow
+    const uint32_t mine = s_cnt[t];
+    __syncthreads();
+    if (mine) s_cnt[t] = (s_suf[t] - a.order_hist[t]) + atomicAdd(&a.order_cursor[t], mine);
+    __syncthreads();
+    if (i != 0xffffffffu) a.tile_order[s_cnt[b] + rank] = i;
 }
 
 // what binning needs to know about one primitive slot
@@ -238,6 +309,11 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && a.ctrl->poison) return;
+    if (FILL && blockIdx.x >= a.bin_blocks) {                   // the grid's last blocks: the raster kernel's tile order
+        static_assert(SWR_BIN_TABLE >= SWR_ORDER_BUCKETS, "tile_place_block borrows the hash table's LDS");
+        tile_place_block(a, blockIdx.x - a.bin_blocks, s_key, s_val);
+        return;
+    }
     const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6, lane_id = threadIdx.x & 63u;
     const bool has_tri = lane_id < a.tpw;
     const uint32_t first = a.slot_lo + (wave_id * a.tpw + lane_id) * a.spt;
@@ -332,8 +408,9 @@ __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long 
 }
 
 __global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
-                                                    unsigned long long* __restrict__ sums) {
+                                                    unsigned long long* __restrict__ sums, uint32_t* __restrict__ order_hist) {
     __shared__ unsigned long long s_part[16];
+    if (blockIdx.x == 0 && threadIdx.x < 2u * SWR_ORDER_BUCKETS) order_hist[threadIdx.x] = 0u;     // histogram + cursors of the tile order (k_scan_apply adds)
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const unsigned long long t = block_sum_1024(i < n ? count[i] : 0u, s_part);
     if (threadIdx.x == 0) sums[blockIdx.x] = t;
@@ -344,17 +421,23 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
                                                      unsigned long long* __restrict__ total_out,
                                                      unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
                                                      Counters* __restrict__ counters, int poison_on_overflow,
-                                                     uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order_hist) {
+                                                     const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order_hist,
+                                                     uint8_t* __restrict__ tile_bucket) {
     __shared__ unsigned long long s_part[16];
     __shared__ unsigned long long s_wave[16];
+    __shared__ uint32_t s_oh[SWR_ORDER_BUCKETS];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    // reset the per-tile work sums (k_cover adds to them) and the histogram / cursors of the tile ordering
-    if (blockIdx.x * 1024u + tid < n) tile_work[blockIdx.x * 1024u + tid] = 0u;
-    if (blockIdx.x == 0 && tid < 2u * SWR_ORDER_BUCKETS) order_hist[tid] = 0u;
+    if (tid < (uint32_t)SWR_ORDER_BUCKETS) s_oh[tid] = 0u;          // (block_sum_1024 below has the barrier)
     // offset of this block = sum of the earlier blocks' sums (gridDim.x <= 1024)
     const unsigned long long off = block_sum_1024(tid < blockIdx.x ? sums[tid] : 0ull, s_part);
     const uint32_t i = blockIdx.x * 1024u + tid;
     const uint32_t c = i < n ? count[i] : 0u;
+    // the tile's place in the raster kernel's dispatch order: bucket of its weight (see order_bucket), histogram of the buckets
+    if (i < n) {
+        const uint32_t ob = order_bucket(tile_weight(tile_work[i], c));
+        tile_bucket[i] = (uint8_t)ob;
+        atomicAdd(&s_oh[ob], 1u);
+    }
     unsigned long long incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -364,6 +447,7 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
     }
     if (lane == 63u) s_wave[wv] = incl;
     __syncthreads();
+    if (tid < (uint32_t)SWR_ORDER_BUCKETS && s_oh[tid]) atomicAdd(&order_hist[tid], s_oh[tid]);
     unsigned long long wave_off = 0;
     for (uint32_t w = 0; w < wv; ++w) wave_off += s_wave[w];
     const unsigned long long excl = off + wave_off + incl - c;
@@ -384,74 +468,6 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
             atomicAdd(&counters->tile_pairs, total);        // MODE_SYNC rounds are counted by the host
         }
     }
-}
-
-// ---- heaviest-first tile order for the raster kernel ---------------------------------------------
-// One wave rasterises one tile and tiles differ a lot in work, so the launch ends with a few long tiles running on
-// an otherwise idle chip.  Workgroups are dispatched in index order as slots free up: handing out the tiles by
-// descending work (fragments counted by k_cover + a per-pair cost) makes that dispatch a longest-first schedule.
-// Counting sort over 8 buckets per octave; the order inside a bucket is arbitrary (tiles are independent).
-__device__ __forceinline__ uint32_t order_bucket(uint32_t w) {
-    if (w == 0u) return 0u;
-    const int e = 31 - __clz((int)w);
-    const uint32_t m = e >= 3 ? ((w >> (e - 3)) & 7u) : ((w << (3 - e)) & 7u);
-    return min((uint32_t)(e * 8) + m + 1u, (uint32_t)SWR_ORDER_BUCKETS - 1u);
-}
-__device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return frags + 16u * pairs; }
-
-// Thread i of the ordering kernels -> tile: a block takes a 16x16-tile region, a wave an 8x8 quarter of it, so that
-// tiles which end up next to each other in the order (same block, same bucket, consecutive LDS ranks) are neighbours
-// on screen: the raster kernel hands runs of 64 consecutive entries to one XCD, whose L2 then serves the triangle
-// records and vertices that neighbouring tiles share.  Returns 0xffffffff outside the band.
-__device__ __forceinline__ uint32_t order_tile_of_thread(int tiles_x, int tiles_y) {
-    const int sbx = (tiles_x + 15) >> 4;
-    const int bx = (int)(blockIdx.x % (uint32_t)sbx), by = (int)(blockIdx.x / (uint32_t)sbx);
-    const int t = threadIdx.x, q = t >> 6, w = t & 63;
-    const int tx = bx * 16 + (q & 1) * 8 + (w & 7), ty = by * 16 + (q >> 1) * 8 + (w >> 3);
-    return (tx < tiles_x && ty < tiles_y) ? (uint32_t)(ty * tiles_x + tx) : 0xffffffffu;
-}
-
-__global__ __launch_bounds__(256) void k_tile_hist(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
-                                                   int tiles_x, int tiles_y, uint32_t* __restrict__ hist, const Ctrl* __restrict__ ctrl) {
-    __shared__ uint32_t s_h[SWR_ORDER_BUCKETS];
-    if (ctrl->poison) return;
-    s_h[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t i = order_tile_of_thread(tiles_x, tiles_y);
-    if (i != 0xffffffffu) atomicAdd(&s_h[order_bucket(tile_weight(tile_work[i], tile_count[i]))], 1u);
-    __syncthreads();
-    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void k_tile_place(const uint32_t* __restrict__ tile_work, const uint32_t* __restrict__ tile_count,
-                                                    int tiles_x, int tiles_y, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor,
-                                                    uint32_t* __restrict__ order, const Ctrl* __restrict__ ctrl) {
-    __shared__ uint32_t s_suf[SWR_ORDER_BUCKETS];     // tiles in heavier buckets (descending order)
-    __shared__ uint32_t s_cnt[SWR_ORDER_BUCKETS];     // this block's tiles per bucket, then their global base
-    if (ctrl->poison) return;
-    const uint32_t t = threadIdx.x;
-    s_suf[t] = hist[t];
-    s_cnt[t] = 0u;
-    __syncthreads();
-    for (uint32_t off = 1; off < (uint32_t)SWR_ORDER_BUCKETS; off <<= 1) {       // inclusive suffix sum
-        const uint32_t v = t + off < (uint32_t)SWR_ORDER_BUCKETS ? s_suf[t + off] : 0u;
-        __syncthreads();
-        s_suf[t] += v;
-        __syncthreads();
-    }
-    const uint32_t i = order_tile_of_thread(tiles_x, tiles_y);
-    uint32_t b = 0, rank = 0;
-    if (i != 0xffffffffu) {
-        b = order_bucket(tile_weight(tile_work[i], tile_count[i]));
-        rank = atomicAdd(&s_cnt[b], 1u);
-    }
-    __syncthreads();
-    // one global reservation per (block, bucket): same-address atomics with a return value are slow
-    const uint32_t mine = s_cnt[t];
-    __syncthreads();
-    if (mine) s_cnt[t] = (s_suf[t] - hist[t]) + atomicAdd(&cursor[t], mine);
-    __syncthreads();
-    if (i != 0xffffffffu) order[s_cnt[b] + rank] = i;
 }
 
 // ---- per-tile ascending sort -------------------------------------------------------------

@@ -193,7 +193,10 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                Counters* __restrict__ counters /* 64 replicas */,
                                                const Ctrl* __restrict__ ctrl, int count_stats, int wireframe,
                                                const uint32_t* __restrict__ visible,
-                                               float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */) {
+                                               float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */,
+                                               uint32_t* __restrict__ zero_words, uint32_t n_zero /* binning's per-tile counters, cleared here
+                                                                                                    instead of by a launch of their own */) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;

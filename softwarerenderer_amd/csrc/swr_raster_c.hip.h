@@ -108,27 +108,46 @@ struct CoverArgs {
     uint4* __restrict__ refs;                 // {slot, vertex references of outputs[0..2]}: the raster kernel's batch set-up
                                               // then needs no load that depends on another load
     const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
-    uint32_t* __restrict__ tile_work;         // per tile: sum of the counts (raster scheduling weight)
     const Ctrl* __restrict__ ctrl;
     FrameParams fp;
+    unsigned long long* dbg;                  // SWR_DEBUG_COVER builds only (tools/debug_counters.py)
 };
 
+// pairs (= threads) per k_cover block, and the quantisation of the shape sort's key (rows, columns)
+#ifndef SWR_COVER_BLOCK
+#define SWR_COVER_BLOCK 256
+#endif
+#ifndef SWR_COVER_HQ
+#define SWR_COVER_HQ 4
+#endif
+#ifndef SWR_COVER_WQ
+#define SWR_COVER_WQ 4
+#endif
 // LINES: the batch is DebugMode.Wireframe (DrawLine records); compiled out of the filled-triangle instantiation
 template <bool LINES>
-__global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
-    __shared__ uint16_t s_rows[256][18];      // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
-    __shared__ uint32_t s_hist[34];           // work sort: pairs per area bucket, then bucket bases
-    __shared__ uint16_t s_perm[256];          // sorted position -> thread whose pair it is
-    __shared__ uint16_t s_cnt[256];           // coverage counts back in pair order
-    __shared__ uint32_t s_wmax[4];            // per wave: widest bbox /\ tile among its lanes on the fast path
+__global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
+    constexpr int CB = SWR_COVER_BLOCK;
+#ifdef SWR_COVER_SORT_AREA
+    constexpr int NB = 33;
+#else
+    constexpr int NB = 1 + (16 / SWR_COVER_HQ) * (16 / SWR_COVER_WQ);
+#endif
+    __shared__ uint16_t s_rows[CB][18];       // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
+    __shared__ uint32_t s_hist[NB];           // work sort: pairs per bucket, then bucket bases
+    __shared__ uint16_t s_perm[CB];           // sorted position -> thread whose pair it is
+    __shared__ uint32_t s_wmax[CB / 64];      // per wave: widest bbox /\ tile among its lanes on the fast path
+#ifdef SWR_DEBUG_COVER
+    __shared__ uint32_t s_hmax[CB / 64];
+    if (threadIdx.x < CB / 64) s_hmax[threadIdx.x] = 0u;
+#endif
     if (a.ctrl->poison) return;
-    const uint32_t p_own = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t p_own = blockIdx.x * (uint32_t)CB + threadIdx.x;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
     // A lane's loop length is the area of bbox /\ tile (1..256 pixels) and a wave runs as long as its longest lane, so
     // the block first sorts its 256 pairs by that area (counting sort in LDS): each wave then holds pairs of similar
     // length.  Results are written at the pair's own index, so nothing downstream sees the permutation.
-    if (threadIdx.x < 34) s_hist[threadIdx.x] = 0u;
-    if (threadIdx.x < 4) s_wmax[threadIdx.x] = 0u;
+    for (int i = threadIdx.x; i < NB; i += CB) s_hist[i] = 0u;
+    if (threadIdx.x < CB / 64) s_wmax[threadIdx.x] = 0u;
     __syncthreads();
     uint32_t bucket = 0, rank = 0;
     {
@@ -145,9 +164,9 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
 #ifndef SWR_COVER_SORT_AREA
             // a wave walks max-height rows x max-width columns of its lanes, so group by SHAPE, not just area: bucket = (rows, columns)
             // quantised to 4 -- 1 + 4 * 4 buckets, tallest / widest first (0 = nothing to walk)
-            if (area > 0) area = 1 + ((h + 3) / 4 - 1) * 4 + ((w + 3) / 4 - 1);
+            if (area > 0) area = 1 + ((h + SWR_COVER_HQ - 1) / SWR_COVER_HQ - 1) * (16 / SWR_COVER_WQ) + ((w + SWR_COVER_WQ - 1) / SWR_COVER_WQ - 1);
         }
-        bucket = (uint32_t)area;                                 // 0..16
+        bucket = (uint32_t)area;                                 // 0..NB-1
 #else
         }
         bucket = (uint32_t)(area + 7) >> 3;                      // 0..32
@@ -157,13 +176,13 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
-        for (int b = 32; b >= 0; --b) { const uint32_t c = s_hist[b]; s_hist[b] = acc; acc += c; }   // longest first
+        for (int b = NB - 1; b >= 0; --b) { const uint32_t c = s_hist[b]; s_hist[b] = acc; acc += c; }   // longest first
     }
     __syncthreads();
     s_perm[s_hist[bucket] + rank] = (uint16_t)threadIdx.x;
     __syncthreads();
     const uint32_t owner = s_perm[threadIdx.x];
-    const uint32_t p = blockIdx.x * 256u + owner;
+    const uint32_t p = blockIdx.x * (uint32_t)CB + owner;
     uint16_t* mrow16 = s_rows[threadIdx.x];
 #pragma unroll
     for (int i = 0; i < 16; ++i) mrow16[i] = 0;
@@ -246,6 +265,10 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
                 // shift-or -- no per-lane loop bookkeeping.  A narrower lane steps past its endX; those values are
                 // never looked at (colmask) and stay finite (<= 31 adds of values below 1e30).
                 const int width = endX - startX + 1;
+#ifdef SWR_DEBUG_COVER
+                atomicMax(&s_hmax[threadIdx.x >> 6], (uint32_t)(endY - startY + 1));
+                atomicAdd(&a.dbg[0], (unsigned long long)(width * (endY - startY + 1)));
+#endif
                 atomicMax(&s_wmax[threadIdx.x >> 6], (uint32_t)width);
                 SWR_WAVE_LDS_FENCE_REAL();        // cold (once per lane and 256-pair block): the real fence costs nothing measurable here
                 const int wsteps = __builtin_amdgcn_readfirstlane((int)s_wmax[threadIdx.x >> 6]);
@@ -314,24 +337,15 @@ __global__ __launch_bounds__(256) void k_cover(CoverArgs a) {
         // selects the k-th pixel of a run arithmetically and searches bit by bit only in pairs without this flag.)
         a.info[p] = make_uint2((uint32_t)cnt | (not_run == 0u ? SWR_INFO_SIMPLE : 0u), __float_as_uint(zbound));
     }
-    s_cnt[owner] = (uint16_t)cnt;
+#ifdef SWR_DEBUG_COVER
     __syncthreads();
-    // raster scheduling weight: fragments per tile.  Back in pair order (pairs are sorted by tile) a wave holds a few
-    // runs of equal tiles: one atomic per run (its last lane adds the run's sum, taken from a wave prefix sum).
-    {
-        const int lane = threadIdx.x & 63;
-        cnt = (int)s_cnt[threadIdx.x];
-        const uint32_t tile = p_own < n_pairs ? a.pair_tile[p_own] : 0xffffffffu;
-        const int incl = wave_incl_scan(cnt, lane);
-        const uint32_t next_tile = (uint32_t)__shfl_down((int)tile, 1);
-        const bool run_end = lane == 63 || next_tile != tile;
-        const uint32_t prev_tile = (uint32_t)__shfl_up((int)tile, 1);
-        const unsigned long long starts = SWR_BALLOT(lane == 0 || prev_tile != tile);
-        const unsigned long long upto = starts & ((2ull << lane) - 1ull);                  // run starts at or below this lane
-        const int first = 63 - __clzll((long long)upto);
-        const int before = __shfl(incl - cnt, first);                                      // prefix before the run
-        if (run_end && tile != 0xffffffffu && incl - before > 0) atomicAdd(&a.tile_work[tile], (uint32_t)(incl - before));
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.dbg[1], (unsigned long long)(64u * s_wmax[threadIdx.x >> 6] * s_hmax[threadIdx.x >> 6]));
+        atomicAdd(&a.dbg[2], 1ull);
     }
+#endif
+    // (round 2 summed the counts per tile here -- the raster kernel's scheduling weight -- with a block barrier, a wave scan and an
+    //  atomic per run of equal tiles; the weight now comes from the raster kernel's own count of the previous flush, swr_binning.hip.h)
 }
 
 // pairs per batch.  Everything a fragment needs from its triangle (the TriRec and the three outputs' varyings)
@@ -483,7 +497,10 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
     const int ty = band_global_row(band_map(a.fp), ty_local);
     const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
     const uint32_t n = a.tile_count[tile];
-    if (n == 0 && !a.clear_color_on && !a.clear_depth_on) return;
+    if (n == 0 && !a.clear_color_on && !a.clear_depth_on) {
+        if (threadIdx.x == 0) a.tile_work[tile] = 0u;
+        return;
+    }
     const uint32_t start = a.tile_start[tile];
     WaveLdsC<PHONG>& L = s_w;
     constexpr bool VG = WaveLdsC<PHONG>::VG;
@@ -1075,6 +1092,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 #ifdef SWR_ABL_PAD
     if (pad0 + pad1 + pad2 + pad3 == 12345.678f) n_tested += 1u;      // keeps the padding alive
 #endif
+    if (lane == 0) a.tile_work[tile] = n_tested;            // the next flush's scheduling weight (k_scan_apply)
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;
         atomicAdd(&ts[0], n_tested); atomicAdd(&ts[1], n_shaded); atomicAdd(&ts[2], n_written);     // no return value: no round trip

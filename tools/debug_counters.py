@@ -7,9 +7,12 @@ lib = os.path.join(ROOT, "softwarerenderer_amd", "libswr_hip.so")
 bak = lib + ".bak"
 shutil.copy(lib, bak)
 try:
-    subprocess.run(["make", "-C", csrc, "-s", "-B", "EXTRA=-DSWR_DEBUG_COUNTERS"], check=True)
+    cover = "--cover" in sys.argv          # k_cover's walk instead: useful pixel steps against executed ones (extra flags may follow)
+    argv = [x for x in sys.argv[1:] if x != "--cover"]
+    extra = " ".join(argv[1:])
+    subprocess.run(["make", "-C", csrc, "-s", "-B", "EXTRA=" + ("-DSWR_DEBUG_COVER " + extra if cover else "-DSWR_DEBUG_COUNTERS")], check=True)
     from softwarerenderer_amd import Device, scenes
-    cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+    cfg = argv[0] if argv else "cfg3"
     scene = getattr(scenes, cfg)()
     dev = Device(0)
     r = scenes.SceneRenderer(dev, scene)
@@ -19,6 +22,11 @@ try:
     r.render()
     dev._lib.swr_debug_counters(dev._ctx, out)
     st = dev.stats()
+    if cover:
+        useful, executed, waves = int(out[0]), int(out[1]), int(out[2])
+        print(cfg, extra, "k_cover walk: lane steps useful", useful, "executed", executed, "ratio", round(executed / max(useful, 1), 3),
+              "steps per wave", round(executed / 64 / max(waves, 1), 1), "useful per lane", round(useful / 64 / max(waves, 1), 1))
+        raise SystemExit(0)
     names = ["batches", "chunks", "max_col_steps", "max_row_steps", "chunk_lanes", "sum_row_steps", "sum_col_steps", "hiz_hidden_fragments"]
     d = dict(zip(names, [int(v) for v in out]))
     print(cfg, d)
