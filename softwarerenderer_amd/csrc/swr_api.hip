@@ -374,7 +374,7 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
     return ba;
 }
 
-// counts_clear: the per-tile counters are already zero (k_setup of this batch cleared them)
+// counts_clear: k_vertex of this batch cleared the per-tile counters and the tile order's histogram (no memsets here)
 int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode, bool counts_clear = false) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
@@ -393,11 +393,14 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     const uint32_t bin_blocks = (bin_threads + 4u * ba.tpw - 1u) / (4u * ba.tpw);
     {
         ScopedSpan sp(c, ST_BIN);
-        if (!counts_clear) SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
+        if (!counts_clear) {
+            SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
+            SWR_HIP(c, hipMemsetAsync(order_hist, 0, 2 * SWR_ORDER_BUCKETS * 4, c->stream));
+        }
         hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
         const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
         unsigned long long* sums = d_total + 32;      // room for 1024 block sums
-        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums, order_hist);
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
         // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
         const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
         hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, ba.tile_count,
@@ -443,8 +446,9 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     }
     {
         ScopedSpan sp(c, ST_SORT);
-        hipLaunchKernelGGL(k_sort_tiles, dim3(n_tiles), dim3(64), 0, c->stream, c->d_tile_start.as<uint32_t>(),
-                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl);
+        hipLaunchKernelGGL(k_sort_tiles, dim3((n_tiles + SWR_SORT_TPB * SWR_SORT_TPW - 1u) / (SWR_SORT_TPB * SWR_SORT_TPW)), dim3(64 * SWR_SORT_TPB), 0, c->stream, c->d_tile_start.as<uint32_t>(),
+                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl,
+                           (const uint32_t*)tile_order);
         SWR_HIP(c, hipGetLastError());
     }
     if (cover_items) {
@@ -626,9 +630,11 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
                            d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible,
                            reinterpret_cast<float*>((char*)c->d_upload.p + offsetof(DrawParams, fog_r1)),
-                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
+                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr, c->d_tile_count.as<uint32_t>(), n_tiles,
+                           c->d_order.as<uint32_t>() + 2 * (size_t)n_tiles);
         SWR_HIP(c, hipGetLastError());
     }
+    const bool counts_clear = !vblocks.empty() && n_tiles != 0;      // k_vertex cleared the per-tile counters and the order histogram
     {
         ScopedSpan sp(c, ST_SETUP);
         hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, c->stream,
@@ -636,11 +642,10 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
                            (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible,
-                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr,
-                           c->d_tile_count.as<uint32_t>(), n_tiles);
+                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode, !tblocks.empty());
+    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode, counts_clear);
     slot_submit(c);
     if (rc) return rc;
     if (cc || cd) return run_clear(c, b, cc, cd, b.clear_rgba);   // nothing was binned

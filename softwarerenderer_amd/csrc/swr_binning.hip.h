@@ -5,7 +5,7 @@
 // pixel (depth ties under `>=`, blending).  The oracle of record is the serial order, so each
 // tile's list must hold its triangles in ascending slot order:
 //   k_bin<COUNT>  : tile_count[tile] += 1 per pair               (integer atomics, order-free)
-//   k_scan        : exclusive scan -> tile_start, total pairs
+//   k_scan        : exclusive scan -> tile_start, total pairs (k_scan_sums + k_scan_apply)
 //   k_bin<FILL>   : list[tile_start + atomic cursor] = slot       (arbitrary order inside a tile)
 //   k_sort_tiles  : one wave per tile sorts its segment ascending (restores submission order)
 // plus the raster kernel's dispatch order (tiles by descending work, a counting sort) without launches of its own: the weight of a
@@ -15,7 +15,7 @@
 #pragma once
 #include "swr_device.h"
 
-#define SWR_ORDER_BUCKETS 256      // heaviest-first tile order: counting-sort buckets (see k_tile_place)
+#define SWR_ORDER_BUCKETS 256      // heaviest-first tile order: counting-sort buckets (see tile_place_block); k_vertex clears 2 x 256 words
 
 namespace swr {
 
@@ -304,6 +304,80 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
 #endif
 #define SWR_BIN_TABLE (1 << SWR_BIN_TABLE_LOG2)     // a block rarely touches more than a few hundred distinct tiles; probing is bounded and
                                                   // a pair that finds no slot goes to the global counter directly
+// one slot per thread of a 256-thread block (slot >= a.slot_hi: nothing); every thread of the block must call
+template <bool FILL>
+__device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot, uint32_t* s_key, uint32_t* s_val) {
+    const SlotData sd = slot_load(a, slot, !FILL);
+    const int nt = sd.nx * sd.ny;
+    const bool big = nt > 8;
+    const int nt_small = big ? 0 : nt;
+    if (!__syncthreads_or(nt != 0)) return;                    // block-uniform (also orders the table's reuse)
+    for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) { s_key[e] = 0u; s_val[e] = 0u; }
+    __syncthreads();
+    // phase 1: every wanted (tile, slot) pair into the table; packed[i] = entry | rank << 12 | wanted << 31
+    uint32_t packed[8];
+    int wtx = sd.tminx, wty = sd.tminy;                         // row-major walk of the tile bbox without integer division
+    uint32_t wmask = (FILL && nt_small) ? (uint32_t)a.want[slot] : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        packed[i] = 0u;
+        if (i < nt_small) {
+            bool want;
+            if (FILL) want = ((wmask >> i) & 1u) != 0u;
+            else {
+                want = band_local_row(a.band, wty) >= 0 && pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
+                wmask |= want ? (1u << i) : 0u;
+            }
+            if (want) {
+                const uint32_t tile = (uint32_t)(band_local_row(a.band, wty) * a.tiles_x + wtx);
+                uint32_t e = (tile * 0x9E3779B1u) >> (32 - SWR_BIN_TABLE_LOG2);
+                bool placed = false;
+                for (int probe = 0; probe < 16; ++probe) {
+                    const uint32_t prev = atomicCAS(&s_key[e], 0u, tile + 1u);
+                    if (prev == 0u || prev == tile + 1u) { placed = true; break; }
+                    e = (e + 1u) & (SWR_BIN_TABLE - 1u);
+                }
+                if (placed) {
+                    const uint32_t rank = atomicAdd(&s_val[e], 1u);       // < 2048
+                    packed[i] = e | (rank << 12) | 0x80000000u;
+                } else if (FILL) {                                      // crowded table (many distinct tiles): go direct
+                    const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
+                    if (at < a.list_capacity) a.tile_list[at] = slot;
+                    else bin_overflow(a);
+                } else {
+                    atomicAdd(&a.tile_count[tile], 1u);
+                }
+            }
+            ++wtx;
+            if (wtx >= sd.tminx + sd.nx) { wtx = sd.tminx; ++wty; }
+        }
+    }
+    if (!FILL && nt_small) a.want[slot] = (uint8_t)wmask;
+    __syncthreads();
+    // phase 2: one global atomic per distinct tile of the block
+    for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) {
+        const uint32_t key = s_key[e];
+        if (key) {
+            const uint32_t tile = key - 1u, n = s_val[e];
+            if (FILL) s_val[e] = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], n);
+            else atomicAdd(&a.tile_count[tile], n);
+        }
+    }
+    if (FILL) {
+        __syncthreads();
+        // phase 3: list position = the tile's base for this block + the pair's rank in the block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (packed[i] & 0x80000000u) {
+                const uint32_t at = s_val[packed[i] & 0xfffu] + ((packed[i] >> 12) & 0x7ffffu);
+                if (at < a.list_capacity) a.tile_list[at] = slot;
+                else bin_overflow(a);
+            }
+        }
+    }
+    bin_big<FILL>(a, sd, slot, big);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
@@ -317,81 +391,13 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6, lane_id = threadIdx.x & 63u;
     const bool has_tri = lane_id < a.tpw;
     const uint32_t first = a.slot_lo + (wave_id * a.tpw + lane_id) * a.spt;
-    for (uint32_t si = 0; si < a.spt; ++si) {
-        const uint32_t slot = has_tri ? first + si : 0xffffffffu;          // >= slot_hi: nothing
-        const SlotData sd = slot_load(a, slot, !FILL);
-        const int nt = sd.nx * sd.ny;
-        const bool big = nt > 8;
-        const int nt_small = big ? 0 : nt;
-        if (!__syncthreads_or(nt != 0)) continue;                  // block-uniform (also orders the table's reuse)
-        for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) { s_key[e] = 0u; s_val[e] = 0u; }
-        __syncthreads();
-        // phase 1: every wanted (tile, slot) pair into the table; packed[i] = entry | rank << 12 | wanted << 31
-        uint32_t packed[8];
-        int wtx = sd.tminx, wty = sd.tminy;                         // row-major walk of the tile bbox without integer division
-        uint32_t wmask = (FILL && nt_small) ? (uint32_t)a.want[slot] : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            packed[i] = 0u;
-            if (i < nt_small) {
-                bool want;
-                if (FILL) want = ((wmask >> i) & 1u) != 0u;
-                else {
-                    want = band_local_row(a.band, wty) >= 0 && pair_may_cover(sd.sx, sd.sy, sd.minX, sd.maxX, sd.minY, sd.maxY, wtx, wty, a.width, a.height, sd.is_line);
-                    wmask |= want ? (1u << i) : 0u;
-                }
-                if (want) {
-                    const uint32_t tile = (uint32_t)(band_local_row(a.band, wty) * a.tiles_x + wtx);
-                    uint32_t e = (tile * 0x9E3779B1u) >> (32 - SWR_BIN_TABLE_LOG2);
-                    bool placed = false;
-                    for (int probe = 0; probe < 16; ++probe) {
-                        const uint32_t prev = atomicCAS(&s_key[e], 0u, tile + 1u);
-                        if (prev == 0u || prev == tile + 1u) { placed = true; break; }
-                        e = (e + 1u) & (SWR_BIN_TABLE - 1u);
-                    }
-                    if (placed) {
-                        const uint32_t rank = atomicAdd(&s_val[e], 1u);       // < 2048
-                        packed[i] = e | (rank << 12) | 0x80000000u;
-                    } else if (FILL) {                                      // crowded table (many distinct tiles): go direct
-                        const uint32_t at = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], 1u);
-                        if (at < a.list_capacity) a.tile_list[at] = slot;
-                        else bin_overflow(a);
-                    } else {
-                        atomicAdd(&a.tile_count[tile], 1u);
-                    }
-                }
-                ++wtx;
-                if (wtx >= sd.tminx + sd.nx) { wtx = sd.tminx; ++wty; }
-            }
-        }
-        if (!FILL && nt_small) a.want[slot] = (uint8_t)wmask;
-        __syncthreads();
-        // phase 2: one global atomic per distinct tile of the block
-        for (int e = threadIdx.x; e < SWR_BIN_TABLE; e += 256) {
-            const uint32_t key = s_key[e];
-            if (key) {
-                const uint32_t tile = key - 1u, n = s_val[e];
-                if (FILL) s_val[e] = a.tile_start[tile] + atomicAdd(&a.tile_count[tile], n);
-                else atomicAdd(&a.tile_count[tile], n);
-            }
-        }
-        if (FILL) {
-            __syncthreads();
-            // phase 3: list position = the tile's base for this block + the pair's rank in the block
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (packed[i] & 0x80000000u) {
-                    const uint32_t at = s_val[packed[i] & 0xfffu] + ((packed[i] >> 12) & 0x7ffffu);
-                    if (at < a.list_capacity) a.tile_list[at] = slot;
-                    else bin_overflow(a);
-                }
-            }
-        }
-        bin_big<FILL>(a, sd, slot, big);
-    }
+    for (uint32_t si = 0; si < a.spt; ++si)
+        bin_block_slots<FILL>(a, has_tri ? first + si : 0xffffffffu, s_key, s_val);          // >= slot_hi: nothing
 }
 
-// Exclusive scan of the per-tile counts in two launches (no inter-block waiting, no dispatch-order assumption):
+// Exclusive scan of the per-tile counts in two launches (no inter-block waiting, no dispatch-order assumption; a single launch that
+// hands out tickets and exchanges the chunk sums through memory was built and measured: 0.0669 against 0.0667 ms for the bin stage --
+// the exchange's dependent round trips cost what the second launch costs -- and it spins, so it was not kept):
 //   k_scan_sums : block b sums its 1024 counts -> sums[b]
 //   k_scan_apply: block b adds sums[0..b) (<= 256 values at 8192^2) to a local scan of its 1024 counts
 __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long* s_part) {
@@ -408,9 +414,8 @@ __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long 
 }
 
 __global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
-                                                    unsigned long long* __restrict__ sums, uint32_t* __restrict__ order_hist) {
+                                                    unsigned long long* __restrict__ sums) {
     __shared__ unsigned long long s_part[16];
-    if (blockIdx.x == 0 && threadIdx.x < 2u * SWR_ORDER_BUCKETS) order_hist[threadIdx.x] = 0u;     // histogram + cursors of the tile order (k_scan_apply adds)
     const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
     const unsigned long long t = block_sum_1024(i < n ? count[i] : 0u, s_part);
     if (threadIdx.x == 0) sums[blockIdx.x] = t;
@@ -489,27 +494,34 @@ __device__ __forceinline__ void cmpx_glb(uint32_t* g, uint32_t i, uint32_t p, ui
     }
 }
 
-// one 64-thread block (one wave) per tile
-__global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
-                                                   const uint32_t* __restrict__ tile_count,
-                                                   uint32_t* __restrict__ tile_list, uint32_t n_tiles,
-                                                   uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl) {
-    __shared__ uint32_t s_keys[SWR_SORT_LDS];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= n_tiles || ctrl->poison) return;
-    const uint32_t n = tile_count[tile];
+// One wave sorts one tile at a time, SWR_SORT_TPW tiles one after the other, SWR_SORT_TPB waves per block (they never meet: no block
+// barrier).  A tile's sort is ~850 cycles of one wave, and 65,536 waves that short are bound by the rate at which waves can be
+// launched (about one per clock chip-wide: 3.5 waves resident per CU on average, 26 us); fewer, longer waves are not.
+#ifndef SWR_SORT_TPB
+#define SWR_SORT_TPB 4
+#endif
+#ifndef SWR_SORT_TPW
+#define SWR_SORT_TPW 4
+#endif
+// what a one-wave workgroup's __syncthreads() amounts to: the wave's own LDS / global accesses complete in order
+#define SWR_SORT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// key_in: entry `lane` of the segment when n <= 64 (the kernel fetches the first 64 entries of all its tiles in one round trip)
+__device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* __restrict__ tile_list, uint32_t tile,
+                                          uint32_t* __restrict__ pair_tile, uint32_t* s_keys, uint32_t key_in) {
     if (n == 0) return;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
     // band-local tile index of every pair of this segment (k_cover reads it): contiguous, coalesced
-    for (uint32_t i = lane; i < n; i += 64) pair_tile[tile_start[tile] + i] = tile;
+#ifndef SWR_ABL_SORT_NOPT
+    for (uint32_t i = lane; i < n; i += 64) pair_tile[start + i] = tile;
+#endif
     if (n < 2) return;
-    uint32_t* seg = tile_list + tile_start[tile];
+    uint32_t* seg = tile_list + start;
 
     if (n <= 64) {
         // In registers.  Partners inside a row of 16 lanes are reached on the DPP path (no LDS round trip): quad_perm for
         // distances 1, 2 and the flip of 4, row_half_mirror / row_mirror for the flips of 8 / 16, row_ror for the xor
         // of 4 / 8; only the three steps that cross rows (flips of 32 and 64, xor 16) go through ds_bpermute.
-        uint32_t key = lane < n ? seg[lane] : 0xffffffffu;
+        uint32_t key = lane < n ? key_in : 0xffffffffu;
 #define SWR_CMPX(other_expr, lower_cond) { const uint32_t other = (uint32_t)(other_expr); \
                                             key = (lower_cond) ? min(key, other) : max(key, other); }
 #define SWR_DPP(ctrl) __builtin_amdgcn_update_dpp(0, (int)key, ctrl, 0xf, 0xf, false)
@@ -519,12 +531,14 @@ __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ 
                     SWR_CMPX((lane & 4u) ? up : dn, (lane & 4u) == 0u) }
 #define SWR_XOR8  SWR_CMPX(SWR_DPP(0x128), (lane & 8u) == 0u)                        /* row_ror:8 */
 #define SWR_XOR16 SWR_CMPX(__shfl((int)key, (int)(lane ^ 16u)), (lane & 16u) == 0u)
+#ifndef SWR_ABL_SORT_NONET          // tools/ablate.py timing experiments only (wrong order by design)
         SWR_XOR1                                                                      // k = 2 (its flip is xor 1)
         SWR_CMPX(SWR_DPP(0x1B), (lane & 2u) == 0u) SWR_XOR1                           // k = 4: flip = quad_perm [3,2,1,0]
         SWR_CMPX(SWR_DPP(0x141), (lane & 4u) == 0u) SWR_XOR2 SWR_XOR1                 // k = 8: flip = row_half_mirror
         SWR_CMPX(SWR_DPP(0x140), (lane & 8u) == 0u) SWR_XOR4 SWR_XOR2 SWR_XOR1        // k = 16: flip = row_mirror
         SWR_CMPX(__shfl((int)key, (int)(lane ^ 31u)), (lane & 16u) == 0u) SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1              // k = 32
         SWR_CMPX(__shfl((int)key, (int)(lane ^ 63u)), (lane & 32u) == 0u) SWR_XOR16 SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1    // k = 64
+#endif
 #undef SWR_XOR16
 #undef SWR_XOR8
 #undef SWR_XOR4
@@ -536,13 +550,16 @@ __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ 
         return;
     }
 
+#ifdef SWR_ABL_SORT_NOBIG
+    return;
+#endif
     uint32_t m = 1;
     while (m < n) m <<= 1;
     const bool in_lds = n <= SWR_SORT_LDS;
     uint32_t* buf = in_lds ? s_keys : seg;
     if (in_lds) {
         for (uint32_t i = lane; i < n; i += 64) s_keys[i] = seg[i];
-        __syncthreads();
+        SWR_SORT_WAVE_SYNC();
     }
     for (uint32_t k = 2; k <= m; k <<= 1) {
         // flip: within each block of k, i in the lower half pairs with block_base + k-1 - offset
@@ -551,19 +568,53 @@ __global__ __launch_bounds__(64) void k_sort_tiles(const uint32_t* __restrict__ 
             uint32_t i = blk * k + off, p = blk * k + (k - 1 - off);
             if (i < n) { if (in_lds) cmpx_lds(buf, i, p, n); else cmpx_glb(buf, i, p, n); }
         }
-        if (!in_lds) __threadfence_block();
-        __syncthreads();
+        SWR_SORT_WAVE_SYNC();
         for (uint32_t j = k >> 2; j > 0; j >>= 1) {
             for (uint32_t t = lane; t < (m >> 1); t += 64) {
                 uint32_t i = 2 * j * (t / j) + (t % j), p = i + j;
                 if (i < n) { if (in_lds) cmpx_lds(buf, i, p, n); else cmpx_glb(buf, i, p, n); }
             }
-            if (!in_lds) __threadfence_block();
-            __syncthreads();
+            SWR_SORT_WAVE_SYNC();
         }
     }
     if (in_lds) {
         for (uint32_t i = lane; i < n; i += 64) seg[i] = s_keys[i];
+    }
+}
+
+__global__ __launch_bounds__(64 * SWR_SORT_TPB) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ tile_count,
+                                                   uint32_t* __restrict__ tile_list, uint32_t n_tiles,
+                                                   uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl,
+                                                   const uint32_t* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
+                                                       pairs sort for 10+ us in one wave and must not start last */) {
+    __shared__ uint32_t s_keys_all[SWR_SORT_TPB][SWR_SORT_LDS];
+    if (ctrl->poison) return;
+    static_assert(SWR_SORT_TPW <= 64, "one lane per tile of the wave fetches its count and start");
+    const uint32_t first = (blockIdx.x * SWR_SORT_TPB + (threadIdx.x >> 6)) * SWR_SORT_TPW;
+    const uint32_t lane = threadIdx.x & 63u;
+    // counts and starts of the wave's tiles in one round trip (lane t: tile first + t)
+#ifdef SWR_SORT_INDEX_ORDER
+    const bool mine = lane < SWR_SORT_TPW && first + lane < n_tiles;
+    const uint32_t tile_l = first + lane;
+#else
+    // wave w takes entries w, w + waves, w + 2 waves, ... of the order: its first tile is among the heaviest, its last among the lightest
+    const uint32_t waves = gridDim.x * SWR_SORT_TPB, entry = (first / SWR_SORT_TPW) + lane * waves;
+    const bool mine = lane < SWR_SORT_TPW && entry < n_tiles;
+    const uint32_t tile_l = mine ? tile_order[entry] : 0u;
+#endif
+    const uint32_t cnt_l = mine ? tile_count[tile_l] : 0u, st_l = mine ? tile_start[tile_l] : 0u;
+    uint32_t keys[SWR_SORT_TPW];           // entry `lane` of every tile's segment: all in flight before the first sort
+#pragma unroll
+    for (int t = 0; t < SWR_SORT_TPW; ++t) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, t), start = (uint32_t)__builtin_amdgcn_readlane((int)st_l, t);
+        keys[t] = (lane < n && n <= 64u) ? tile_list[start + lane] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int t = 0; t < SWR_SORT_TPW; ++t) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)cnt_l, t), start = (uint32_t)__builtin_amdgcn_readlane((int)st_l, t);
+        sort_tile(n, start, tile_list, (uint32_t)__builtin_amdgcn_readlane((int)tile_l, t), pair_tile, s_keys_all[threadIdx.x >> 6], keys[t]);
+        SWR_SORT_WAVE_SYNC();              // the next tile reuses the wave's LDS slice
     }
 }
 

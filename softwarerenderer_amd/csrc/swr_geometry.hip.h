@@ -24,7 +24,13 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
                                                 VOut* __restrict__ vout, const uint32_t* __restrict__ visible,
                                                 float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */,
                                                 float4* __restrict__ vnorm /* VertexOutput.Normal per VOut entry, or null: only batches
-                                                                              with a DEBUG_VARYINGS draw carry it (see VOut) */) {
+                                                                              with a DEBUG_VARYINGS draw carry it (see VOut) */,
+                                                uint32_t* __restrict__ zero_words, uint32_t n_zero /* binning's per-tile counters: cleared
+                                                                              here, not by a launch of their own */,
+                                                uint32_t* __restrict__ zero_hist /* and the tile order's histogram + cursors */) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
+    if (blockIdx.x == 0) { zero_hist[threadIdx.x] = 0u; zero_hist[256 + threadIdx.x] = 0u; }
+    // (2 x SWR_ORDER_BUCKETS words, swr_binning.hip.h)
     const BlockMap bm = blocks[blockIdx.x];
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
@@ -193,10 +199,7 @@ __global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ dr
                                                Counters* __restrict__ counters /* 64 replicas */,
                                                const Ctrl* __restrict__ ctrl, int count_stats, int wireframe,
                                                const uint32_t* __restrict__ visible,
-                                               float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */,
-                                               uint32_t* __restrict__ zero_words, uint32_t n_zero /* binning's per-tile counters, cleared here
-                                                                                                    instead of by a launch of their own */) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
+                                               float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */) {
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;

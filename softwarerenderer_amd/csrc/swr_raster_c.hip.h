@@ -17,7 +17,7 @@
 //   Pairs are taken 16 at a time: one lane per pair fetches the triangle record and the three outputs ONCE and
 //   stages what fragments need in LDS (per-fragment gathers through the vector L1 were the first bound), pairs that
 //   provably fail the depth test everywhere are dropped against the tile's minimum stored depth (hi-Z), and tiles
-//   are dispatched heaviest first (k_tile_hist / k_tile_place in swr_binning.hip.h).
+//   are dispatched heaviest first (tile_place_block in swr_binning.hip.h).
 //   A wave's time per chunk is a chain of dependent LDS / memory round trips that four waves per SIMD (LDS: 10 KB per wave) do
 //   not cover, so the links that can run early do: the next window's head words are read at the cut, each lane's next pair and
 //   that pair's prefix counts between replay and shading, the row-start table and stored depth ahead of the election's atomic.
