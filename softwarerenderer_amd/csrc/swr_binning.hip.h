@@ -64,10 +64,14 @@ struct BinArgs {
 // float M' satisfies M' >= M(1-4u).  With delta = 64uM':
 //   Efl_max < -delta  =>  W <= E_max + 35uM <= Efl_max + 41uM < -64uM(1-4u) + 41uM < 0 on all of R  (kills "all >= 0")
 //   Efl_min >  delta  =>  W > 0 on all of R                                                          (kills "all <= 0")
-// NaN / Inf inputs make the finiteness test or the comparisons false, i.e. "keep".
+// The analysis needs every product and sum finite: screen coordinates below 1e15 in magnitude (tested once per triangle, not
+// per tile and edge as in round 2) bound every term by 1e31; anything else (NaN / Inf included) means "keep".
 __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy[3], int minX, int maxX, int minY, int maxY,
                                                int tx, int ty, int width, int height, bool is_line) {
     if (is_line) return true;         // DrawLine edges: keep every tile of the line's bbox (the test below is for triangles)
+#ifdef SWR_ABL_NOPMC                  // tools/ablate.py timing experiments only
+    return true;
+#endif
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
     const int startX = max(minX, x0), endX = min(maxX, min(x0 + SWR_TILE - 1, width - 1));
     const int startY = max(minY, y0), endY = min(maxY, min(y0 + SWR_TILE - 1, height - 1));
@@ -78,6 +82,9 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
     const float rx[3] = { sx[1], sx[2], sx[0] };
     const float ry[3] = { sy[1], sy[2], sy[0] };
     const float fxs = (float)startX, fxe = (float)endX, fys = (float)startY, fye = (float)endY;
+    const float lim = 1.0e15f;
+    const bool tame = fabsf(sx[0]) < lim && fabsf(sx[1]) < lim && fabsf(sx[2]) < lim && fabsf(sy[0]) < lim && fabsf(sy[1]) < lim && fabsf(sy[2]) < lim;
+    if (!tame) return true;
     bool any_neg = false, any_pos = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -88,10 +95,8 @@ __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy
         const float emin = fminf(ax_s, ax_e) + fminf(by_s, by_e);
         const float m = fabsf(a) * fmaxf(fabsf(dxs), fabsf(dxe)) + fabsf(b) * fmaxf(fabsf(dys), fabsf(dye));
         const float delta = m * (64.0f / 16777216.0f);
-        // fmaxf/fminf drop NaNs, so test finiteness explicitly: a non-finite term means "cannot prove anything"
-        const bool finite = m < 1.0e30f && ax_s == ax_s && ax_e == ax_e && by_s == by_s && by_e == by_e;
-        any_neg = any_neg || (finite && emax < -delta);
-        any_pos = any_pos || (finite && emin > delta);
+        any_neg = any_neg || emax < -delta;
+        any_pos = any_pos || emin > delta;
     }
     return !(any_neg && any_pos);
 }
@@ -300,7 +305,7 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
 // global atomic per distinct tile leaves the block; FILL gets each pair's rank from the LDS add and the tile's base
 // from that one global atomic.  The order inside a tile's list is irrelevant here (k_sort_tiles restores it).
 #ifndef SWR_BIN_TABLE_LOG2
-#define SWR_BIN_TABLE_LOG2 9
+#define SWR_BIN_TABLE_LOG2 8
 #endif
 #define SWR_BIN_TABLE (1 << SWR_BIN_TABLE_LOG2)     // a block rarely touches more than a few hundred distinct tiles; probing is bounded and
                                                   // a pair that finds no slot goes to the global counter directly
