@@ -188,7 +188,10 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 #else
 #define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
 #endif
-__global__ __launch_bounds__(256) void k_setup(const DrawParams* __restrict__ draws,
+#ifndef SWR_SETUP_MINBLOCKS
+#define SWR_SETUP_MINBLOCKS 1
+#endif
+__global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
                                                VOut* __restrict__ clip_pool,     // 4 VOut per triangle, indexed by global triangle
