@@ -205,9 +205,10 @@ __device__ __forceinline__ bool slot_tiles(const BinArgs& a, unsigned long long 
     return true;
 }
 // with_rec = false: only the tile bbox (FILL of a small triangle replays COUNT's decisions from a.want)
-__device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot, bool with_rec_small) {
+// tb = a.slot_tb[slot] (SWR_TB_INVALID for a slot outside the round): the caller fetches it one slot ahead
+__device__ __forceinline__ SlotData slot_load(const BinArgs& a, uint32_t slot, unsigned long long tb, bool with_rec_small) {
     SlotData s = slot_none();
-    if (slot < a.slot_hi && slot_tiles(a, a.slot_tb[slot], s) && (with_rec_small || s.nx * s.ny > 8)) {
+    if (slot_tiles(a, tb, s) && (with_rec_small || s.nx * s.ny > 8)) {
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
         const float4 r0 = rq[0], r1 = rq[1], r3 = rq[3];
         s.sx[0] = r0.x; s.sx[1] = r0.y; s.sx[2] = r0.z; s.sy[0] = r0.w; s.sy[1] = r1.x; s.sy[2] = r1.y;
@@ -309,10 +310,10 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
 #endif
 #define SWR_BIN_TABLE (1 << SWR_BIN_TABLE_LOG2)     // a block rarely touches more than a few hundred distinct tiles; probing is bounded and
                                                   // a pair that finds no slot goes to the global counter directly
-// one slot per thread of a 256-thread block (slot >= a.slot_hi: nothing); every thread of the block must call
+// one slot per thread of a 256-thread block (tb = its tile bbox word, SWR_TB_INVALID: nothing); every thread of the block must call
 template <bool FILL>
-__device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot, uint32_t* s_key, uint32_t* s_val) {
-    const SlotData sd = slot_load(a, slot, !FILL);
+__device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot, unsigned long long tb, uint32_t want_in, uint32_t* s_key, uint32_t* s_val) {
+    const SlotData sd = slot_load(a, slot, tb, !FILL);
     const int nt = sd.nx * sd.ny;
     const bool big = nt > 8;
     const int nt_small = big ? 0 : nt;
@@ -322,7 +323,7 @@ __device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot,
     // phase 1: every wanted (tile, slot) pair into the table; packed[i] = entry | rank << 12 | wanted << 31
     uint32_t packed[8];
     int wtx = sd.tminx, wty = sd.tminy;                         // row-major walk of the tile bbox without integer division
-    uint32_t wmask = (FILL && nt_small) ? (uint32_t)a.want[slot] : 0u;
+    uint32_t wmask = (FILL && nt_small) ? want_in : 0u;            // FILL: COUNT's decisions (a.want[slot], fetched with tb)
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         packed[i] = 0u;
@@ -396,8 +397,19 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     const uint32_t wave_id = (blockIdx.x * 256u + threadIdx.x) >> 6, lane_id = threadIdx.x & 63u;
     const bool has_tri = lane_id < a.tpw;
     const uint32_t first = a.slot_lo + (wave_id * a.tpw + lane_id) * a.spt;
-    for (uint32_t si = 0; si < a.spt; ++si)
-        bin_block_slots<FILL>(a, has_tri ? first + si : 0xffffffffu, s_key, s_val);          // >= slot_hi: nothing
+    // the tile bbox word of slot si + 1 is on its way while slot si is binned (a block's life is a chain of memory round trips and
+    // barriers: this takes one round trip out of every slot but the first)
+    auto in_round = [&](uint32_t si) { return has_tri && si < a.spt && first + si < a.slot_hi; };
+    auto tb_of = [&](uint32_t si) { return in_round(si) ? a.slot_tb[first + si] : SWR_TB_INVALID; };
+    auto want_of = [&](uint32_t si) { return (FILL && in_round(si)) ? (uint32_t)a.want[first + si] : 0u; };   // (a byte of a slot COUNT never wrote is never used)
+    unsigned long long tb = tb_of(0);
+    uint32_t wm = want_of(0);
+    for (uint32_t si = 0; si < a.spt; ++si) {
+        const unsigned long long tb_next = tb_of(si + 1);
+        const uint32_t wm_next = want_of(si + 1);
+        bin_block_slots<FILL>(a, first + si, tb, wm, s_key, s_val);
+        tb = tb_next; wm = wm_next;
+    }
 }
 
 // Exclusive scan of the per-tile counts in two launches (no inter-block waiting, no dispatch-order assumption; a single launch that

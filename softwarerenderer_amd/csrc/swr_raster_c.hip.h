@@ -135,6 +135,9 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     __shared__ uint16_t s_rows[CB][18];       // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
     __shared__ uint32_t s_hist[NB];           // work sort: pairs per bucket, then bucket bases
     __shared__ uint16_t s_perm[CB];           // sorted position -> thread whose pair it is
+#ifndef SWR_COVER_NO_EXCHANGE
+    __shared__ uint32_t s_slot[CB], s_tile[CB];   // the pair's list entries, read once in pair order and handed to the lane that walks it
+#endif
     __shared__ uint32_t s_wmax[CB / 64];      // per wave: widest bbox /\ tile among its lanes on the fast path
 #ifdef SWR_DEBUG_COVER
     __shared__ uint32_t s_hmax[CB / 64];
@@ -154,6 +157,9 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         int area = 0;
         if (p_own < n_pairs) {
             const uint32_t slot = a.tile_list[p_own], tile = a.pair_tile[p_own];
+#ifndef SWR_COVER_NO_EXCHANGE
+            s_slot[threadIdx.x] = slot; s_tile[threadIdx.x] = tile;
+#endif
             const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
             const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
             const float4 r3 = reinterpret_cast<const float4*>(a.recs + slot)[3];
@@ -188,8 +194,12 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     for (int i = 0; i < 16; ++i) mrow16[i] = 0;
     int cnt = 0;
     if (p < n_pairs) {
+#ifndef SWR_COVER_NO_EXCHANGE
+        const uint32_t slot = s_slot[owner], tile = s_tile[owner];      // (written before the sort's barriers)
+#else
         const uint32_t slot = a.tile_list[p];
         const uint32_t tile = a.pair_tile[p];
+#endif
         const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
         const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
