@@ -35,18 +35,49 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
+#ifndef SWR_VERTEX_DIRECT_STORES
+    // A lane's 64-byte record leaves as four 16-byte stores, 64 bytes apart from its neighbour's: 256 partial line writes per wave.
+    // The wave's 64 records go through LDS instead and leave as four stores of 1 KB each (consecutive lanes, consecutive 16 bytes).
+    // (and the other way round for the 48-byte input vertices: three loads of 1 KB each per wave, handed out through LDS)
+    __shared__ float4 s_out[4][256];
+    float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
+    const bool live = local < dp->n_verts;
+    const uint32_t wv_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63u;
+    const uint32_t first_ = bm.first + wv_ * 64u;                // first vertex of the wave
+    const uint32_t n_live_ = dp->n_verts > first_ ? min(dp->n_verts - first_, 64u) : 0u;
+#ifndef SWR_VERTEX_DIRECT_LOADS
+    {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(dp->verts + first_);
+        float4* sw = &s_out[wv_][0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t e = (uint32_t)k * 64u + lane_;
+            if (e < 3u * n_live_) sw[e] = src[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+#endif
+    if (live) {
+#else
     if (local >= dp->n_verts) return;
+    {
+#endif
     if (local == 0u) {      // once per draw: the refined reciprocal of the fog range (see div_core in swr_device.h)
         const float den = dp->u.fog_end - dp->u.fog_start;
         fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float))] = div_operand_safe(den) ? rcp_refined(den) : 0.0f;
         fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float)) + 3] = den;      // DrawParams::fog_den
     }
 
+#if !defined(SWR_VERTEX_DIRECT_STORES) && !defined(SWR_VERTEX_DIRECT_LOADS)
+    const float4 q0 = s_out[wv_][3 * lane_], q1 = s_out[wv_][3 * lane_ + 1], q2 = s_out[wv_][3 * lane_ + 2];   // pos.xyz uv.x | uv.y normal.xyz | color
+#else
     const float* __restrict__ vin = reinterpret_cast<const float*>(dp->verts + local);
     // 48-byte vertex = three 16-byte loads
     const float4 q0 = *reinterpret_cast<const float4*>(vin);       // pos.xyz, uv.x
     const float4 q1 = *reinterpret_cast<const float4*>(vin + 4);   // uv.y, normal.xyz
     const float4 q2 = *reinterpret_cast<const float4*>(vin + 8);   // color
+#endif
 
     float p[4] = { q0.x, q0.y, q0.z, 1.0f };
     float world[4], viewp[4], clip[4];
@@ -57,12 +88,38 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
     vec3_transform_normal(n, dp->model, tn);    // :835
     float len = sqrtf(dot3(tn[0], tn[1], tn[2], tn[0], tn[1], tn[2]));   // Vector3.Normalize = v / Length()
 
+#ifdef SWR_VERTEX_DIRECT_STORES
     float4* o = reinterpret_cast<float4*>(vout + dp->vert_base + local);
     o[0] = make_float4(clip[0], clip[1], clip[2], clip[3]);
     o[1] = q2;
     o[2] = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
     o[3] = make_float4(tn[2] / len, world[0], world[1], world[2]);
+#else
+    o0 = make_float4(clip[0], clip[1], clip[2], clip[3]);
+    o1 = q2;
+    o2 = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
+    o3 = make_float4(tn[2] / len, world[0], world[1], world[2]);
+#endif
     if (vnorm) vnorm[dp->vert_base + local] = make_float4(n[0], n[1], n[2], 0.0f);      // Normal = input.Normal, Renderer.cs:842
+    }
+#ifndef SWR_VERTEX_DIRECT_STORES
+    {
+        const uint32_t wv = wv_, lane = lane_;
+        float4* sw = &s_out[wv][0];                       // the wave's 64 records: record l = entries 4 l .. 4 l + 3
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (the input vertices above have been read by every lane)
+        __builtin_amdgcn_wave_barrier();
+        sw[4 * lane + 0] = o0; sw[4 * lane + 1] = o1; sw[4 * lane + 2] = o2; sw[4 * lane + 3] = o3;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // one wave: its own LDS accesses complete in order
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t first = first_, n_live = n_live_;
+        float4* dst = reinterpret_cast<float4*>(vout + dp->vert_base + first);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t e = (uint32_t)k * 64u + lane;
+            if ((e >> 2) < n_live) dst[e] = sw[e];
+        }
+    }
+#endif
 }
 
 // a vertex moving through clip + setup: the stored varyings plus the Interpolate flag
@@ -109,7 +166,9 @@ __device__ __forceinline__ void load_vout(const VOut* __restrict__ src, VOut& v)
 __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, uint32_t draw,
                                               const SVert& v0, const SVert& v1, const SVert& v2,
                                               uint32_t r0, uint32_t r1, uint32_t r2,
-                                              TriRec* __restrict__ rec, unsigned long long* __restrict__ tb, bool wireframe) {
+                                              TriRec* __restrict__ rec, unsigned long long* __restrict__ tb, bool wireframe,
+                                              float4* __restrict__ rec_regs = nullptr /* filled mode: the record goes here instead of to
+                                                                                         memory (k_setup stores a wave's records together) */) {
     const int rw = fp.width, rh = fp.height;
     // outputs = { v2, v1, v0 }  (Rasterizer.cs:367)
     const SVert* o[3] = { &v2, &v1, &v0 };
@@ -166,7 +225,11 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
     int maxY = min(f2i(ceilf(maxYf)), rh - 1);
     if (minX > maxX || minY > maxY) return 0;                                            // :442
 
-    float4* out = reinterpret_cast<float4*>(rec);
+    float4* out = rec_regs ? rec_regs : reinterpret_cast<float4*>(rec);
+#ifdef SWR_ABL_SETUP_NOSTORE           // tools/ablate.py timing experiments only
+    if (inv_area == 12345.678f)
+#endif
+    {
     out[0] = make_float4(sx[0], sx[1], sx[2], sy[0]);
     out[1] = make_float4(sy[1], sy[2], dz[0], dz[1]);
     out[2] = make_float4(dz[2], inv_area, __uint_as_float(r2), __uint_as_float(r1));    // vref = outputs order
@@ -174,6 +237,7 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
                          __uint_as_float((uint32_t)minX | ((uint32_t)maxX << 16)),
                          __uint_as_float((uint32_t)minY | ((uint32_t)maxY << 16)),
                          __uint_as_float(flags));
+    }
     // tile bbox (Rasterizer.cs:449-452), 16 bits each: tminx | tmaxx<<16 | tminy<<32 | tmaxy<<48
     tb[0] = (unsigned long long)(minX / SWR_TILE) | ((unsigned long long)(maxX / SWR_TILE) << 16) |
             ((unsigned long long)(minY / SWR_TILE) << 32) | ((unsigned long long)(maxY / SWR_TILE) << 48);
@@ -210,6 +274,9 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
     const bool drawn = !visible || visible[bm.draw] != 0u;     // frustum-culled draws: slots invalid, nothing counted
     const bool active = in_range && drawn;
     unsigned n_setup = 0, n_clipped = 0;
+    // the record of an unclipped filled triangle (nearly all): kept in registers and stored by the wave together, see the end
+    float4 rec_q[4] = { make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f) };
+    bool rec_valid = false;
 
     if (in_range && !drawn) {
         const uint32_t per_fan = wireframe ? 3u : 1u;
@@ -287,6 +354,12 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
                                                           pbase, pbase + 2, pbase + 3, recs + slot + per_fan, &tbs[3], wireframe != 0);
                 }
             } else {
+#ifndef SWR_SETUP_DIRECT_STORES
+                if (!wireframe) {
+                    rec_valid = setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], false, rec_q) != 0;
+                    n_setup += rec_valid ? 1u : 0u;
+                } else
+#endif
                 n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], wireframe != 0);
             }
         }
@@ -299,6 +372,28 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
         }
     }
 
+#ifndef SWR_SETUP_DIRECT_STORES
+    // A lane's 64-byte TriRec would leave as four 16-byte stores, 128 bytes apart from its neighbour's (256 partial line writes per
+    // wave: 16 of the kernel's 37 us).  The wave's records go through LDS and leave as four stores of sixteen whole records each.
+    {
+        __shared__ float4 s_rec[4][256];
+        const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const unsigned long long vmask = __ballot(rec_valid);
+        if (vmask) {                                                   // wave-uniform
+            float4* sw = &s_rec[wv][0];
+            sw[4 * lane + 0] = rec_q[0]; sw[4 * lane + 1] = rec_q[1]; sw[4 * lane + 2] = rec_q[2]; sw[4 * lane + 3] = rec_q[3];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // one wave: its own LDS accesses complete in order
+            __builtin_amdgcn_wave_barrier();
+            // lane j's triangle is dp->tri_base + bm.first + 64 wv + j, its record slot twice that (filled mode: two slots per triangle)
+            float4* dst = reinterpret_cast<float4*>(recs + 2u * (size_t)(dp->tri_base + bm.first + wv * 64u));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t e = (uint32_t)k * 64u + lane, j = e >> 2;
+                if ((vmask >> j) & 1ull) dst[8u * j + (e & 3u)] = sw[e];
+            }
+        }
+    }
+#endif
     // block-level counter reduction, then one atomic per counter per block into a replica
     __shared__ unsigned s_cnt[3];
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
-        const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];
+        const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];      // (r3 through LDS as well: no change, measured)
         a.refs[p] = make_uint4(slot, __float_as_uint(r2.z), __float_as_uint(r2.w), __float_as_uint(r3.x));
         const float s0x = r0.x, s1x = r0.y, s2x = r0.z, s0y = r0.w, s1y = r1.x, s2y = r1.y;
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
