@@ -367,8 +367,7 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
 #pragma unroll
             for (int k = 0; k < 6; ++k) slot_tb[slot + k] = tbs[k];
         } else {
-            slot_tb[slot] = tbs[0];
-            slot_tb[slot + 1] = tbs[3];
+            *reinterpret_cast<ulonglong2*>(slot_tb + slot) = make_ulonglong2(tbs[0], tbs[3]);      // slot is even: one 16-byte store
         }
     }
 

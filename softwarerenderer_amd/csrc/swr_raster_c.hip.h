@@ -138,6 +138,13 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
 #ifndef SWR_COVER_NO_EXCHANGE
     __shared__ uint32_t s_slot[CB], s_tile[CB];   // the pair's list entries, read once in pair order and handed to the lane that walks it
 #endif
+    // Results leave in PAIR order, not in the walk's sorted order: the walking lane leaves its rows in the LDS row of the pair's own
+    // thread and its hi-Z bound in s_zb, and after a barrier thread t packs and stores pair t -- consecutive lanes, consecutive
+    // addresses (in sorted order every lane's 16-byte stores went to a different line: k_cover is memory bound, and scattered
+    // partial-line writes are what cost k_setup 16 of its 37 us).  SWR_COVER_SORTED_OUT: round 2's stores (A/B).
+#ifndef SWR_COVER_SORTED_OUT
+    __shared__ float s_zb[CB];
+#endif
     __shared__ uint32_t s_wmax[CB / 64];      // per wave: widest bbox /\ tile among its lanes on the fast path
 #ifdef SWR_DEBUG_COVER
     __shared__ uint32_t s_hmax[CB / 64];
@@ -163,6 +170,12 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
             const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
             const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
             const float4 r3 = reinterpret_cast<const float4*>(a.recs + slot)[3];
+#ifndef SWR_COVER_SORTED_OUT
+            {   // {slot, vertex references of outputs[0..2]}: words 10, 11, 12 of the TriRec
+                const float2 r2zw = reinterpret_cast<const float2*>(a.recs + slot)[5];
+                a.refs[p_own] = make_uint4(slot, __float_as_uint(r2zw.x), __float_as_uint(r2zw.y), __float_as_uint(r3.x));
+            }
+#endif
             const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
             const int w = min((int)(bbx >> 16), min(x0 + SWR_TILE - 1, a.fp.width - 1)) - max((int)(bbx & 0xffffu), x0) + 1;
             const int h = min((int)(bby >> 16), min(y0 + SWR_TILE - 1, a.fp.height - 1)) - max((int)(bby & 0xffffu), y0) + 1;
@@ -189,10 +202,38 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     __syncthreads();
     const uint32_t owner = s_perm[threadIdx.x];
     const uint32_t p = blockIdx.x * (uint32_t)CB + owner;
+#ifndef SWR_COVER_SORTED_OUT
+    uint16_t* mrow16 = s_rows[owner];
+#else
     uint16_t* mrow16 = s_rows[threadIdx.x];
+#endif
 #pragma unroll
     for (int i = 0; i < 16; ++i) mrow16[i] = 0;
-    int cnt = 0;
+    // pack 16 row masks into the pair's 256-bit mask, count them, flag rows that are not one run; store mask and info of pair `pi`
+    auto emit = [&a](const uint16_t* rows, uint32_t pi, float zb) {
+        uint32_t mw[8];
+        int cnt = 0;
+#ifdef SWR_NO_SIMPLE_SELECT                    // test builds: every pair takes the raster kernel's general k-th-set-bit search
+        uint32_t not_run = 1u;
+#else
+        uint32_t not_run = 0u;                 // a row whose covered pixels are not ONE run leaves a bit here
+#endif
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {          // word i = rows 2i (low half) and 2i+1 (high half)
+            const uint32_t lo = rows[2 * i], hi = rows[2 * i + 1];
+            not_run |= (lo & (lo + (lo & (0u - lo)))) | (hi & (hi + (hi & (0u - hi))));
+            mw[i] = lo | (hi << 16);
+            cnt += __popc(mw[i]);
+        }
+        if (cnt) {                             // (the raster kernel drops an empty pair before it looks at its mask)
+            a.masks[2 * (size_t)pi] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
+            a.masks[2 * (size_t)pi + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
+        }
+        // (along a row every edge value is monotone -- it is stepped by a constant -- so "all >= 0" and "all <= 0" are
+        // intervals and a row is one run unless both are non-empty and apart: sliver triangles only.  The raster kernel
+        // selects the k-th pixel of a run arithmetically and searches bit by bit only in pairs without this flag.)
+        a.info[pi] = make_uint2((uint32_t)cnt | (not_run == 0u ? SWR_INFO_SIMPLE : 0u), __float_as_uint(zb));
+    };
     if (p < n_pairs) {
 #ifndef SWR_COVER_NO_EXCHANGE
         const uint32_t slot = s_slot[owner], tile = s_tile[owner];      // (written before the sort's barriers)
@@ -205,7 +246,9 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
         const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];      // (r3 through LDS as well: no change, measured)
+#ifdef SWR_COVER_SORTED_OUT
         a.refs[p] = make_uint4(slot, __float_as_uint(r2.z), __float_as_uint(r2.w), __float_as_uint(r3.x));
+#endif
         const float s0x = r0.x, s1x = r0.y, s2x = r0.z, s0y = r0.w, s1y = r1.x, s2y = r1.y;
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
@@ -327,28 +370,16 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
                 }
             }
         }
-        uint32_t mw[8];
-#ifdef SWR_NO_SIMPLE_SELECT                    // test builds: every pair takes the raster kernel's general k-th-set-bit search
-        uint32_t not_run = 1u;
+#ifdef SWR_COVER_SORTED_OUT
+        emit(mrow16, p, zbound);
 #else
-        uint32_t not_run = 0u;                 // a row whose covered pixels are not ONE run leaves a bit here
+        s_zb[owner] = zbound;
 #endif
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {          // word i = rows 2i (low half) and 2i+1 (high half)
-            const uint32_t lo = mrow16[2 * i], hi = mrow16[2 * i + 1];
-            not_run |= (lo & (lo + (lo & (0u - lo)))) | (hi & (hi + (hi & (0u - hi))));
-            mw[i] = lo | (hi << 16);
-            cnt += __popc(mw[i]);
-        }
-        if (cnt) {                             // (the raster kernel drops an empty pair before it looks at its mask)
-            a.masks[2 * (size_t)p] = make_uint4(mw[0], mw[1], mw[2], mw[3]);
-            a.masks[2 * (size_t)p + 1] = make_uint4(mw[4], mw[5], mw[6], mw[7]);
-        }
-        // (along a row every edge value is monotone -- it is stepped by a constant -- so "all >= 0" and "all <= 0" are
-        // intervals and a row is one run unless both are non-empty and apart: sliver triangles only.  The raster kernel
-        // selects the k-th pixel of a run arithmetically and searches bit by bit only in pairs without this flag.)
-        a.info[p] = make_uint2((uint32_t)cnt | (not_run == 0u ? SWR_INFO_SIMPLE : 0u), __float_as_uint(zbound));
     }
+#ifndef SWR_COVER_SORTED_OUT
+    __syncthreads();
+    if (p_own < n_pairs) emit(s_rows[threadIdx.x], p_own, s_zb[threadIdx.x]);
+#endif
 #ifdef SWR_DEBUG_COVER
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
