@@ -465,7 +465,8 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ca.fp = frame_params(c);
         ca.fp.near_clip = b.near_clip;
         ca.dbg = d_total + 8;
-        const dim3 cg((unsigned)((cover_items + (uint32_t)SWR_COVER_BLOCK - 1u) / (uint32_t)SWR_COVER_BLOCK)), cb(SWR_COVER_BLOCK);
+        // (a multiple of 8 blocks: the kernel hands XCD x the x-th contiguous eighth of the blocks that hold pairs)
+        const dim3 cg((unsigned)((((cover_items + (uint32_t)SWR_COVER_BLOCK - 1u) / (uint32_t)SWR_COVER_BLOCK) + 7u) & ~7u)), cb(SWR_COVER_BLOCK);
         if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, cg, cb, 0, c->stream, ca);
         else hipLaunchKernelGGL(k_cover<false>, cg, cb, 0, c->stream, ca);
         SWR_HIP(c, hipGetLastError());

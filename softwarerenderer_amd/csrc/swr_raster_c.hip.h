@@ -151,8 +151,23 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     if (threadIdx.x < CB / 64) s_hmax[threadIdx.x] = 0u;
 #endif
     if (a.ctrl->poison) return;
-    const uint32_t p_own = blockIdx.x * (uint32_t)CB + threadIdx.x;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
+    // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own, and a triangle's pairs sit in neighbouring tiles: the one to
+    // the right a few dozen pairs away, the one below a whole tile row (thousands of pairs) away.  XCD x therefore takes the x-th
+    // CONTIGUOUS eighth of the pair array (of the pairs that exist, not of the grid, which covers the list capacity): the block that
+    // meets a TriRec again a tile row later runs on the same XCD while the line is still in its L2.  SWR_COVER_LINEAR_BLOCKS: A/B.
+#ifndef SWR_COVER_LINEAR_BLOCKS
+    uint32_t block;
+    {
+        const uint32_t nb = (n_pairs + (uint32_t)CB - 1u) / (uint32_t)CB, per_xcd = (nb + 7u) >> 3;
+        const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+        if (k >= per_xcd) return;                                   // (block-uniform)
+        block = xcd * per_xcd + k;
+    }
+#else
+    const uint32_t block = blockIdx.x;
+#endif
+    const uint32_t p_own = block * (uint32_t)CB + threadIdx.x;
     // A lane's loop length is the area of bbox /\ tile (1..256 pixels) and a wave runs as long as its longest lane, so
     // the block first sorts its 256 pairs by that area (counting sort in LDS): each wave then holds pairs of similar
     // length.  Results are written at the pair's own index, so nothing downstream sees the permutation.
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     s_perm[s_hist[bucket] + rank] = (uint16_t)threadIdx.x;
     __syncthreads();
     const uint32_t owner = s_perm[threadIdx.x];
-    const uint32_t p = blockIdx.x * (uint32_t)CB + owner;
+    const uint32_t p = block * (uint32_t)CB + owner;
 #ifndef SWR_COVER_SORTED_OUT
     uint16_t* mrow16 = s_rows[owner];
 #else
