@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.." || exit 1
 O=gpurun_out/ab_setup2.txt; : > $O
-ABLATE_N=30 python3 tools/ablate.py cfg3 "" "-DSWR_ABL_SETUP_NOSTORE" "-DSWR_ABL_SETUP_DENSE" "" >> $O 2>&1
+ABLATE_N=30 python3 tools/ablate.py cfg3 "" "-DSWR_ABL_SETUP_NOSTORE" "" >> $O 2>&1
 cat $O
