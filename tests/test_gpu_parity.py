@@ -346,3 +346,14 @@ def test_debug_varyings_in_wireframe_is_refused_not_wrong(device):
         Rasterizer.RenderDebugMode = DebugMode.None_
     device.sync()
     run_both(device, scenes.cfg2(200, 120, 300, seed=74))          # the context is fine afterwards
+
+
+def test_tile_order_history_of_another_scene_changes_nothing(device):
+    """The raster kernel's dispatch order takes its per-tile weights from the PREVIOUS flush on the device (any permutation of the tiles
+    is correct, swr_binning.hip.h).  Frames of unrelated scenes of one size -- the history of one is the other's -- a resize in between
+    (which drops the history) and the same scene twice in a row must each equal the oracle."""
+    a = scenes.cfg3(384, 320, (3, 3), (24, 16), tex_size=64, seed=21)                 # many small textured triangles
+    b = scenes.cfg2(384, 320, 300, seed=22, min_area=500.0, max_area=40000.0)         # few big ones: very different tile weights
+    c = scenes.cfg2(200, 136, 400, seed=23)                                           # another size: another tiling
+    for scene in (a, b, a, a, c, b, b):
+        run_both(device, scene)
