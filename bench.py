@@ -70,6 +70,17 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend; gloo (control plane only, needs --gather p2p) rehearses the N>1 path with "
                          "several ranks on ONE GPU (SWR_BENCH_ONE_DEVICE=1), which RCCL refuses")
+    ap.add_argument("--pipelining", type=int, choices=[0, 1, 2], default=1,
+                    help="frames in flight inside the library (swr_set_pipelining): 1 (default) = the front end of frame i+1 runs on a second "
+                         "stream beside the raster kernel of frame i, 0 = one stream, 2 = as 1 with the front stream at default priority")
+    ap.add_argument("--camera-jitter", type=float, default=0.0,
+                    help="perturb the view matrix of every frame on the host (a translation of this amplitude in view space plus a small "
+                         "yaw, a different one each frame): the tile order feeds on the previous frame's fragment counts, this shows it is "
+                         "not fitted to a repeated frame")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1 only: take the N>1 code path end to end with a world of ONE rank on the nccl (RCCL) backend -- "
+                         "init_process_group, SetBand, two bound band buffers, async dist.gather, work.wait(), the all-reduced replay "
+                         "flag on the GPU, record_stream, checkpoint / resend: the RCCL leg rehearsed on the one GPU of a test box")
     ap.add_argument("--print-src-hash", action="store_true", help="print the kernel-source hash (tools/profile_round.sh) and exit")
     args = ap.parse_args()
     if args.print_src_hash:
@@ -84,6 +95,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         args.gpus = world
+    if args.force_dist and (world != 1 or args.fake_world > 1):
+        raise SystemExit("--force-dist is the one-rank rehearsal of the N>1 path: use it with --gpus 1 and without --fake-world")
+    dist_on = world > 1 or args.force_dist          # the multi-GPU code path (bands, band buffers, gather, checkpoints)
 
     import torch                      # plumbing: device memory for the bands, streams, RCCL
     import torch.distributed as dist
@@ -107,6 +121,14 @@ def main():
     if os.environ.get("SWR_BENCH_ONE_DEVICE", "0") == "1":
         local_rank = 0                    # rehearsal: every rank on GPU 0 (at most 6 processes may share a card on this pool)
     torch.cuda.set_device(local_rank)
+    if args.force_dist:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     if world > 1 and not args.fake_world:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "gloo":
@@ -122,10 +144,11 @@ def main():
     scene = build_scene(args.config, args)
     W, H = scene.width, scene.height
     dev = Device(local_rank)
+    dev.set_pipelining(args.pipelining)
     window = MainWindow(dev, W, H)
     color_t = depth_t = None
-    overlap = world > 1 and os.environ.get("SWR_BENCH_OVERLAP", "1") != "0"
-    if world > 1:
+    overlap = dist_on and os.environ.get("SWR_BENCH_OVERLAP", "1") != "0"
+    if dist_on:
         band = multigpu.band_partition(H, world)[rank]
         rows = multigpu.max_band_rows(H, world)
         if args.stripes > 0:
@@ -140,13 +163,13 @@ def main():
         else:
             window.SetBand(*band)
         window.BindFramebuffer(color_t[0].data_ptr(), depth_t[0].data_ptr())
-    p2p = world > 1 and args.gather == "p2p"
-    rgb = world > 1 and args.gather in ("rgb32f", "p2p")
+    p2p = dist_on and args.gather == "p2p"
+    rgb = dist_on and args.gather in ("rgb32f", "p2p")
     chan = 3 if rgb else 4
     rgb_t = [torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(len(color_t))] if (rgb and not p2p) else None
-    frame_t = torch.empty((H, W, chan), dtype=torch.float32, device="cuda") if (world > 1 and rank == 0) else None
+    frame_t = torch.empty((H, W, chan), dtype=torch.float32, device="cuda") if (dist_on and rank == 0) else None
     peer_rows = None
-    if world > 1:
+    if dist_on:
         # render, flatten and the consumer of the band run in stream order on torch's current stream: no host round trip
         # between a frame's last kernel and its gather (optimistic flushes are validated later, see validate_previous)
         # (a stream of its own: torch's default stream is the NULL stream, which swr_set_stream reads as "context's own")
@@ -169,8 +192,8 @@ def main():
         peer_rows = peer_frame[y0:y0 + nrows]              # contiguous rows of rank 0's frame = this rank's band
     renderer = scenes.SceneRenderer(dev, scene, window=window)
     state = {"i": 0, "works": [None] * (len(color_t) if color_t else 1), "ev": [], "since_check": 0,
-             "replays": dev.replay_count() if world > 1 else 0, "resent": 0, "last_k": None}
-    xfer = torch.cuda.Stream() if world > 1 else None      # rank 0: post-collective assembly (stripes / unequal bands), off the render stream
+             "replays": dev.replay_count() if dist_on else 0, "resent": 0, "last_k": None, "frame_no": 0}
+    xfer = torch.cuda.Stream() if dist_on else None      # rank 0: post-collective assembly (stripes / unequal bands), off the render stream
     stripe_bufs = None
 
     def send_band(k):
@@ -193,7 +216,8 @@ def main():
                     w.wait()
                     multigpu.assemble_stripes(stripe_bufs[k], H, world, args.stripes, frame=frame_t)
             return w
-        return multigpu.gather_bands(payload, H, W, rank, world, dst=0, frame=frame_t, dist=dist, async_op=True, post_stream=xfer)[1]
+        return multigpu.gather_bands(payload, H, W, rank, world, dst=0, frame=frame_t, dist=dist, async_op=True, post_stream=xfer,
+                                     force_collective=args.force_dist)[1]
 
     def before_reuse(k):
         """buffer k was last used two frames ago: its transfer must be over before the next frame renders into it.  A stream-level
@@ -214,13 +238,13 @@ def main():
         torch.cuda.current_stream().synchronize()
         if xfer is not None:
             xfer.synchronize()
-        if world > 1 and not args.fake_world:
+        if dist_on and not args.fake_world:
             dist.barrier()
         dev.sync()
         r = dev.replay_count()
-        replayed = world > 1 and r != state["replays"]
+        replayed = dist_on and r != state["replays"]
         state["replays"] = r
-        if world > 1 and not args.fake_world:
+        if dist_on and not args.fake_world:
             # the re-send below is a collective in the RCCL modes and a store into rank 0's frame in p2p mode: every rank has to
             # know whether ANY rank replayed, take part, and meet again before rank 0 may read its frame
             flag = torch.tensor([1 if replayed else 0], dtype=torch.int32, device="cpu" if args.backend == "gloo" else "cuda")
@@ -245,7 +269,10 @@ def main():
         torch.cuda.synchronize()
 
     def step():
-        if world == 1:
+        if args.camera_jitter > 0.0:
+            renderer.jitter_views(state["frame_no"], args.camera_jitter)
+        state["frame_no"] += 1
+        if not dist_on:
             renderer.submit_frame()
             dev.flush()
             return
@@ -274,7 +301,7 @@ def main():
     t_prime = time.perf_counter()
     n_prime = 0
     # (the count must be the same on every rank: only a single process may extend it by wall time)
-    while n_prime < args.prime or (world == 1 and time.perf_counter() - t_prime < 0.2 and n_prime < 10 * args.prime):
+    while n_prime < args.prime or (not dist_on and time.perf_counter() - t_prime < 0.2 and n_prime < 10 * args.prime):
         step()
         dev.sync()
         n_prime += 1
@@ -285,7 +312,10 @@ def main():
     dev.reset_stats()
     if not args.no_profile_events:
         dev.profile_reset()
-        dev.profile_enable(3)          # hipEvents around the dominant kernel of every 4th step: an event pair costs ~10 us of stream time
+        # hipEvents around the dominant kernel, on the stream it is launched on: on EVERY launch of a short timed region (the driver's
+        # 20 steps: a mean of 5 samples moved by 7 % between two passes of one run), on every 4th launch of a long one (an event pair
+        # costs ~10 us of stream time)
+        dev.profile_enable(2 if args.steps <= 32 else 3)
     barrier()
     state["ev"] = []
     t0 = time.perf_counter()
@@ -293,12 +323,32 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    render_s = 1e-3 * sum(a.elapsed_time(b) for a, b in state["ev"]) if world > 1 else 0.0
+    render_s = 1e-3 * sum(a.elapsed_time(b) for a, b in state["ev"]) if dist_on else 0.0
     prof = dev.profile() if not args.no_profile_events else None
+    samples = np.sort(dev.raster_samples()) if not args.no_profile_events else None
     st = dev.stats()
     stage_ms = None
+    isolated = None
     if not args.no_profile_events:
-        # per-stage breakdown from a few extra frames OUTSIDE the timed region (events around every stage)
+        # OUTSIDE the timed region, frames NOT in flight (one stream: a kernel has the chip to itself, which is what a kernel's
+        # roofline is quoted on): (1) the raster kernel of every launch of as many frames as were timed, and the frame time,
+        # (2) a per-stage breakdown from a few frames with events around every stage
+        dev.set_pipelining(0)
+        n_iso = max(8, min(args.steps, 64))
+        for _ in range(3):
+            step()
+        barrier()
+        dev.profile_reset(); dev.profile_enable(2)
+        t_iso = time.perf_counter()
+        for _ in range(n_iso):
+            step()
+        barrier()
+        t_iso = time.perf_counter() - t_iso
+        iso = np.sort(dev.raster_samples())
+        if iso.size:
+            isolated = {"raster_ms_median": round(float(np.median(iso)), 4), "raster_ms_min": round(float(iso[0]), 4),
+                        "raster_ms_max": round(float(iso[-1]), 4), "launches": int(iso.size),
+                        "ms_per_step_unpipelined": round(1e3 * t_iso / n_iso, 4)}
         dev.profile_reset(); dev.profile_enable(1)
         n_extra = 5
         for _ in range(n_extra):
@@ -308,12 +358,13 @@ def main():
         stage_ms = {k: round(p2[k] / n_extra, 4) for k in
                     ("vertex_ms", "setup_ms", "bin_ms", "sort_ms", "cover_ms", "raster_ms", "clear_ms", "total_ms")}
         dev.profile_enable(0)
+        dev.set_pipelining(args.pipelining)
 
     # whole-job numbers: max time over ranks, fragments summed over ranks
-    red_dev = "cpu" if (world > 1 and args.backend == "gloo" and not args.fake_world) else "cuda"
+    red_dev = "cpu" if (dist_on and args.backend == "gloo" and not args.fake_world) else "cuda"
     counts = torch.tensor([st["fragments_tested"], st["fragments_written"], st["tile_pairs"]], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([elapsed, render_s], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax[0].item())
@@ -339,30 +390,35 @@ def main():
                                    f"{('2048^2 RGBA8 ' + ('bilinear (build-defined) ' if scene.bilinear else 'nearest ') + 'texture, ') if scene.textures else ''}"
                                    f"program {scene.draws[0].program.name}, {scene.draws[0].cull.name}/"
                                    f"{scene.draws[0].depth_test.name}/{scene.draws[0].blend.name}",
-                       "parallelism": "1 GPU" if world == 1 else (f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0" if not p2p else
+                       "pipelining": args.pipelining, "camera_jitter": args.camera_jitter,
+                       "parallelism": "1 GPU" if not dist_on else (f"{world} tile-row bands + RCCL gather of the {args.gather} frame to rank 0" if not p2p else
                                       f"{world} tile-row bands, each rank's flatten kernel stores its rgb32f band into rank 0's frame through a peer-mapped pointer (xGMI), barrier every 32 frames")
                                       + (" (gather of frame i overlaps rendering of frame i+1)" if overlap else "")
                                       + f"; gather_payload={args.gather}, {4 * chan} B/pixel",
-                       "gather_payload": None if world == 1 else args.gather,
-                       "gather_bytes_per_pixel": None if world == 1 else 4 * chan},
+                       "gather_payload": None if not dist_on else args.gather,
+                       "gather_bytes_per_pixel": None if not dist_on else 4 * chan},
             "mtriangles_per_s": round(n_tris / (ms_per_step * 1e-3) / 1e6, 3),
             "fragments_tested_per_frame": int(frags_tested),
             "fragments_written_per_frame": int(frags_written),
             "tile_pairs_per_frame": int(counts[2].item() / args.steps),
             "device": dev.name,
         }
-        if world > 1:
+        if dist_on:
             # the two legs of a multi-GPU step: rendering the bands (slowest rank, wall time until its band is final)
             # and the xGMI gather of the frame into rank 0, which overlaps the next frame's rendering
             out["multi_gpu"] = {"render_ms_per_step": round(1e3 * render_s / args.steps, 4),
                                 "gather_payload": args.gather, "frames_resent_after_replay": state["resent"],
-                                "gather_mb_per_frame_into_rank0": round(H * W * chan * 4 * (world - 1) / world / 1e6, 1)}
-        if prof is not None and prof["raster_launches"] > 0:
-            # dominant kernel = k_raster; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1)
-            raster_ms = prof["raster_ms"] / prof["raster_launches"]
+                                "gather_mb_per_frame_into_rank0": round(H * W * chan * 4 * (world - 1) / world / 1e6, 1),
+                                "forced_one_rank_rehearsal": bool(args.force_dist),
+                                "model": multi_gpu_model(args.config, world, H, W, chan)}
+        if prof is not None and prof["raster_launches"] > 0 and samples is not None and samples.size:
+            # dominant kernel = k_raster_c; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1).  Its duration is the
+            # MEDIAN of the per-launch hipEvent samples of the timed region, i.e. with frames in flight when pipelining is on: the
+            # kernel then shares the chip with the next frame's front end, so the one-stream figure rides along (kernel_ms_isolated)
+            raster_ms = float(np.median(samples))
             written_local = st["fragments_written"] / args.steps
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
-            frame_bytes = (W * H if world == 1 else color_t[0].shape[0] * W) * 20.0
+            frame_bytes = (W * H if not dist_on else color_t[0].shape[0] * W) * 20.0
             traffic, traffic_detail = pmc_traffic(args.config, world)
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_raster_c",
@@ -373,22 +429,38 @@ def main():
                 "traffic_unit": "GB per launch = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this build (null: none for this build); algorithmic = written fragments x 20 B",
                 "algorithmic_gb_per_launch": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / 1e9, 4),
                 "kernel_ms": round(raster_ms, 4),
-                "kernel_launches_timed": int(prof["raster_launches"]),      # every 4th launch of the timed region carries an event pair
+                "kernel_ms_median": round(raster_ms, 4), "kernel_ms_min": round(float(samples[0]), 4), "kernel_ms_max": round(float(samples[-1]), 4),
+                "kernel_ms_mean": round(prof["raster_ms"] / prof["raster_launches"], 4),
+                "kernel_launches_timed": int(samples.size),      # every launch of a timed region of <= 32 steps, else every 4th
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": stage_ms,
             }
-            vf = valu_floor(args.config, world, raster_ms, written_local)
+            if isolated is not None:
+                iso_ms = isolated["raster_ms_median"]
+                out["roofline"]["kernel_ms_isolated"] = iso_ms
+                out["roofline"]["raster_ms_isolated"] = iso_ms
+                out["roofline"]["frac_isolated"] = round(written_local * BYTES_PER_WRITTEN_FRAGMENT / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                out["roofline"]["isolated"] = isolated
+                rel = abs(raster_ms - iso_ms) / iso_ms
+                if rel > 0.03:
+                    out["roofline"]["warning"] = (f"timed-region kernel_ms and the one-stream kernel_ms_isolated differ by {100 * rel:.1f} %"
+                                                  + (": expected with frames in flight (the kernel shares the chip with the next frame's front end)"
+                                                     if args.pipelining else ": measurement noise above 3 %"))
+            vf = valu_floor(args.config, world, isolated["raster_ms_median"] if isolated else raster_ms, written_local)
             if vf is not None:
                 out["roofline"]["valu_floor"] = vf
-        if world == 1 and not args.no_cpu_baseline:
+        if isolated is not None:
+            out["ms_per_step_unpipelined"] = isolated["ms_per_step_unpipelined"]
+        if not dist_on and not args.no_cpu_baseline:
+            renderer.jitter_views(0, 0.0)              # the comparison frame is the unperturbed one
             out["cpu_baseline"] = cpu_baseline(scene, renderer, np)
         print(json.dumps(out), flush=True)
 
-    if rank == 0 and world > 1 and os.environ.get("SWR_BENCH_DUMP_FRAME"):     # tests: the frame rank 0 holds after the last step
+    if rank == 0 and dist_on and os.environ.get("SWR_BENCH_DUMP_FRAME"):     # tests: the frame rank 0 holds after the last step
         np.save(os.environ["SWR_BENCH_DUMP_FRAME"], frame_t.cpu().numpy())
     renderer.close()
     dev.close()
-    if world > 1 and not args.fake_world:
+    if dist_on and not args.fake_world:
         dist.destroy_process_group()
 
 
@@ -412,6 +484,36 @@ def launch_ranks_if_needed(args, argv, run=None):
     env.setdefault("OMP_NUM_THREADS", "1")
     r = (run or subprocess.run)(cmd, env=env, cwd=ROOT)
     return int(r.returncode)
+
+
+XGMI_LINK_GBS = 64.0            # one xGMI link, one direction, as RCCL send/recv sustains it (64-77 GB/s)
+
+
+def multi_gpu_model(config, world, H, W, chan):
+    """What DESIGN.md section 6 predicts for this N, printed next to what was measured so that a SCALE run can be read line by line:
+    every rank runs the vertex + setup stages for ALL triangles and bins / sorts / covers / rasterises its band (1/N of the pairs);
+    frames are pipelined, so a rank's render leg is max(front end, raster); all N-1 bands travel to rank 0 concurrently, one xGMI
+    link each.  Stage times: the newest committed single-GPU line of this config (profiles/r*_bench_with_cpu.json); null if none."""
+    import glob
+    gather_ms = (H * W * chan * 4.0 / max(world, 1)) / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0
+    out = {"link_gb_s": XGMI_LINK_GBS, "gather_ms": round(gather_ms, 4), "render_ms": None, "step_ms": None, "source": None}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_final_bench_with_cpu.json")), reverse=True):
+        try:
+            j = json.load(open(path))
+            stg = j["roofline"]["stage_ms_per_step"]
+            if not j["config"]["workload"].startswith(config + ":"):
+                continue
+        except Exception:
+            continue
+        replicated = stg["vertex_ms"] + stg["setup_ms"]
+        banded = stg["bin_ms"] + stg["sort_ms"] + stg["cover_ms"]
+        front = replicated + banded / world
+        raster = stg["raster_ms"] / world
+        render = max(front, raster) if j["config"].get("pipelining", 0) else front + raster
+        out.update({"render_ms": round(render, 4), "front_ms": round(front, 4), "raster_ms": round(raster, 4),
+                    "step_ms": round(max(render, gather_ms), 4), "source": os.path.basename(path)})
+        break
+    return out
 
 
 def kernel_source_hash():

@@ -85,7 +85,7 @@ namespace SoftwareRenderer
 
     public enum SwrProgram { FlatColor = 0, Gouraud = 1, Dust2LambertFog = 2, Phong4Point = 3, DebugVaryings = 4 }
 
-    // ---------------------------------------------------------------- the 49 entry points ----
+    // ---------------------------------------------------------------- the 59 entry points ----
     // Shaders.VertexInput (Shaders.cs:10-24) IS swr_vertex: four sequential System.Numerics fields, 48 bytes, blittable.
     // Matrix4x4 is 16 sequential floats M11..M44 (row-major, row-vector convention): passed by address, no marshalling.
     internal static unsafe class Native
@@ -94,6 +94,8 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_abi_version();
         [DllImport(Lib)] public static extern IntPtr swr_build_info();
         [DllImport(Lib)] public static extern int swr_numerics_mode(out int fma, out int dotOrder);
+        [DllImport(Lib)] public static extern int swr_set_transform_fma(IntPtr ctx, int transformFused, int transformNormalFused);
+        [DllImport(Lib)] public static extern int swr_get_transform_fma(IntPtr ctx, out int transformFused, out int transformNormalFused);
         [DllImport(Lib)] public static extern IntPtr swr_last_error(IntPtr ctx);
         [DllImport(Lib)] public static extern int swr_create(int deviceId, out IntPtr ctx);
         [DllImport(Lib)] public static extern void swr_destroy(IntPtr ctx);
@@ -135,6 +137,8 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_is_sphere_in_frustum(IntPtr ctx, Vector4* centerRadius, Matrix4x4* model, Matrix4x4* view, Matrix4x4* projection, out int inside);
         [DllImport(Lib)] public static extern int swr_render_mesh_culled(IntPtr ctx, IntPtr mesh, Matrix4x4* model, Matrix4x4* view, Matrix4x4* projection, int program, SwrUniforms* uniforms, IntPtr texture, int cullMode, int depthTest, int blendMode);
         [DllImport(Lib)] public static extern int swr_flush(IntPtr ctx);
+        [DllImport(Lib)] public static extern int swr_set_pipelining(IntPtr ctx, int mode);
+        [DllImport(Lib)] public static extern int swr_get_pipelining(IntPtr ctx, out int mode);
         [DllImport(Lib)] public static extern int swr_sync(IntPtr ctx);
         [DllImport(Lib)] public static extern int swr_interpolate(IntPtr ctx, float* verts60, float* w, int n, int interpolate, float* outRecords);
         [DllImport(Lib)] public static extern int swr_get_stats(IntPtr ctx, out SwrStats stats);
@@ -142,6 +146,7 @@ namespace SoftwareRenderer
         [DllImport(Lib)] public static extern int swr_profile_enable(IntPtr ctx, int on);
         [DllImport(Lib)] public static extern int swr_profile_get(IntPtr ctx, out SwrProfile profile);
         [DllImport(Lib)] public static extern int swr_profile_reset(IntPtr ctx);
+        [DllImport(Lib)] public static extern int swr_profile_raster_samples(IntPtr ctx, float* outMs, int capacity, out int n);
         [DllImport(Lib)] public static extern int swr_device_name(IntPtr ctx, byte* buf, int buflen);
         [DllImport(Lib)] public static extern int swr_selftest_division(IntPtr ctx, ulong samples, ulong seed, ulong* out8);
         [DllImport(Lib)] public static extern int swr_debug_counters(IntPtr ctx, ulong* out8);
@@ -150,18 +155,22 @@ namespace SoftwareRenderer
     // ---------------------------------------------------------------- numerics probe ----
     // Nothing in the reference's repository pins how .NET 9 evaluates Vector4.Transform / Vector4.Lerp (with fused multiply-adds or
     // without) and Vector3.Dot (in which order the lanes are summed), and a third of a real frame's depth words depend on the first
-    // question (DESIGN.md section 3).  The backend is built in every model (libswr_hip.so = unfused + sequential, _fma, _dotpw,
-    // _fma_dotpw, _dpps); at start-up the three operations are evaluated with the RUNNING System.Numerics on operands on which the
-    // models give different float32 bits, and the library built for the observed model is the one `swr_hip` resolves to.  A pattern
-    // that no build models (e.g. Lerp fused but Transform not) throws: better no picture than a frame that silently differs.
+    // question (DESIGN.md section 3).  The three fused-or-not questions (Transform, TransformNormal, Lerp) and the dot order are
+    // modelled INDEPENDENTLY: Lerp x dot order picks one of six builds (libswr_hip.so = unfused + sequential, _fma, _dotpw,
+    // _fma_dotpw, _dpps, _fma_dpps), Transform / TransformNormal are run-time flags of the context (swr_set_transform_fma).  At
+    // start-up the operations are evaluated with the RUNNING System.Numerics on operands on which the models give different float32
+    // bits; the library built for the observed (Lerp, Dot) model is the one `swr_hip` resolves to and the context gets the observed
+    // Transform flags: all 24 combinations are served.  Only a bit pattern that is NEITHER model's throws.
     public static class NumericsProbe
     {
         // <generated by tools/make_numerics_probe.py -- do not edit; tests/test_abi.py compares with csharp/numerics_probe.json>
         const uint LerpA = 0xC00CEF08u, LerpB = 0xBED29EFEu, LerpT = 0x3F478017u, LerpUnfused = 0xBF4E7C50u, LerpFused = 0xBF4E7C4Fu;
         static readonly uint[] TransformV = { 0xC06E43E7u, 0xC00C65BDu, 0x3EF222FCu, 0xBF9FF980u }, TransformColumn = { 0x3FA4C6C1u, 0x3F79740Cu, 0x3FC9D8E3u, 0xC06C7478u };
         const uint TransformUnfused = 0xBFC88EB0u, TransformFused = 0xBFC88EACu;
-        static readonly uint[] DotA = { 0x404E9543u, 0xBE0E5810u, 0x3FC0BF7Cu }, DotB = { 0x3F68F07Eu, 0x3EE1EC4Bu, 0xC03AC7F0u };
-        const uint DotSequential = 0xBFC26DE8u, DotShuffle = 0xBFC26DE9u;
+        static readonly uint[] TransformNormalN = { 0x404E9543u, 0xBE0E5810u, 0x3FC0BF7Cu }, TransformNormalColumn = { 0x3F68F07Eu, 0x3EE1EC4Bu, 0xC03AC7F0u };
+        const uint TransformNormalUnfused = 0xBFC26DE8u, TransformNormalFused = 0xBFC26DE7u;
+        static readonly uint[] DotA = { 0xC0230FD7u, 0x3FC580AFu, 0x3F8C55D4u }, DotB = { 0xC02E1034u, 0x4069FD33u, 0x3FE786D7u };
+        const uint DotSequential = 0x4168DCA9u, DotShuffle = 0x4168DCA8u;
         static readonly uint[] DotZeroA = { 0x80000000u, 0x80000000u, 0x80000000u }, DotZeroB = { 0x3F800000u, 0x3F800000u, 0x3F800000u };
         const uint DotZeroSequential = 0x80000000u, DotZeroDpps = 0x00000000u;
         // </generated>
@@ -170,33 +179,36 @@ namespace SoftwareRenderer
         static float F(uint bits) => BitConverter.UInt32BitsToSingle(bits ^ salt);
         static uint B(float f) => BitConverter.SingleToUInt32Bits(f);
 
-        /// (fma, dotOrder) of the running System.Numerics in the terms of swr_numerics_mode; throws on an unknown pattern.
+        /// The running System.Numerics in the terms of swr_numerics_mode (lerpFused = *fma, dotOrder) and of swr_set_transform_fma
+        /// (transformFused, transformNormalFused); throws on a bit pattern that neither model of an operation produces.
         [MethodImpl(MethodImplOptions.NoInlining)]
-        public static (int fma, int dotOrder) Observe()
+        public static (int lerpFused, int transformFused, int transformNormalFused, int dotOrder) Observe()
         {
             uint lerp = B(Vector4.Lerp(new Vector4(F(LerpA)), new Vector4(F(LerpB)), F(LerpT)).X);
             var m = new Matrix4x4(F(TransformColumn[0]), 0, 0, 0, F(TransformColumn[1]), 0, 0, 0, F(TransformColumn[2]), 0, 0, 0, F(TransformColumn[3]), 0, 0, 0);
             uint tr = B(Vector4.Transform(new Vector4(F(TransformV[0]), F(TransformV[1]), F(TransformV[2]), F(TransformV[3])), m).X);
+            var mn = new Matrix4x4(F(TransformNormalColumn[0]), 0, 0, 0, F(TransformNormalColumn[1]), 0, 0, 0, F(TransformNormalColumn[2]), 0, 0, 0, 0, 0, 0, 1);
+            uint tn = B(Vector3.TransformNormal(new Vector3(F(TransformNormalN[0]), F(TransformNormalN[1]), F(TransformNormalN[2])), mn).X);
             uint dot = B(Vector3.Dot(new Vector3(F(DotA[0]), F(DotA[1]), F(DotA[2])), new Vector3(F(DotB[0]), F(DotB[1]), F(DotB[2]))));
             uint dz = B(Vector3.Dot(new Vector3(F(DotZeroA[0]), F(DotZeroA[1]), F(DotZeroA[2])), new Vector3(F(DotZeroB[0]), F(DotZeroB[1]), F(DotZeroB[2]))));
             int lerpFused = lerp == LerpFused ? 1 : lerp == LerpUnfused ? 0 : -1;
             int trFused = tr == TransformFused ? 1 : tr == TransformUnfused ? 0 : -1;
-            if (lerpFused < 0 || trFused < 0 || lerpFused != trFused)
-                throw new NotSupportedException($"System.Numerics model not built: Lerp -> 0x{lerp:X8}, Transform -> 0x{tr:X8} (see csharp/numerics_probe.json)");
+            int tnFused = tn == TransformNormalFused ? 1 : tn == TransformNormalUnfused ? 0 : -1;
+            if (lerpFused < 0 || trFused < 0 || tnFused < 0)
+                throw new NotSupportedException($"System.Numerics model not built: Lerp -> 0x{lerp:X8}, Transform -> 0x{tr:X8}, TransformNormal -> 0x{tn:X8} (see csharp/numerics_probe.json)");
             int order;
             if (dot == DotShuffle) order = 2;
             else if (dot == DotSequential) order = dz == DotZeroDpps ? 1 : dz == DotZeroSequential ? 0 : -1;
             else order = -1;
             if (order < 0) throw new NotSupportedException($"System.Numerics model not built: Dot -> 0x{dot:X8} / 0x{dz:X8} (see csharp/numerics_probe.json)");
-            if (lerpFused == 1 && order == 1) throw new NotSupportedException("System.Numerics model not built: fused multiply-adds with the dpps dot order");
-            return (lerpFused, order);
+            return (lerpFused, trFused, tnFused, order);
         }
 
-        /// File name of the build that models the running System.Numerics.
+        /// File name of the build that models the running System.Numerics' Lerp and Dot (six builds: every combination exists).
         public static string SelectLibrary()
         {
-            var (fma, order) = Observe();
-            string suffix = (fma == 1 ? "_fma" : "") + (order == 2 ? "_dotpw" : order == 1 ? "_dpps" : "");
+            var (lerpFused, _, _, order) = Observe();
+            string suffix = (lerpFused == 1 ? "_fma" : "") + (order == 2 ? "_dotpw" : order == 1 ? "_dpps" : "");
             return "libswr_hip" + suffix + ".so";
         }
 
@@ -206,9 +218,16 @@ namespace SoftwareRenderer
             string file = SelectLibrary();
             NativeLibrary.SetDllImportResolver(typeof(NumericsProbe).Assembly, (name, assembly, path) =>
                 name == "swr_hip" ? NativeLibrary.Load(System.IO.Path.Combine(AppContext.BaseDirectory, file)) : IntPtr.Zero);
-            var (fma, order) = Observe();
-            if (Native.swr_numerics_mode(out int libFma, out int libOrder) != 0 || libFma != fma || libOrder != order)
-                throw new InvalidOperationException($"{file} was built for fma={libFma}, dot={libOrder}; the probe observed fma={fma}, dot={order}");
+            var (lerpFused, _, _, order) = Observe();
+            if (Native.swr_numerics_mode(out int libFma, out int libOrder) != 0 || libFma != lerpFused || libOrder != order)
+                throw new InvalidOperationException($"{file} was built for fma={libFma}, dot={libOrder}; the probe observed fma={lerpFused}, dot={order}");
+        }
+
+        /// The run-time half of the model: the observed Transform / TransformNormal flags go to the context (after swr_create).
+        public static void Configure(IntPtr ctx)
+        {
+            var (_, trFused, tnFused, _) = Observe();
+            if (Native.swr_set_transform_fma(ctx, trFused, tnFused) != 0) throw new InvalidOperationException("swr_set_transform_fma failed");
         }
     }
 
@@ -227,9 +246,10 @@ namespace SoftwareRenderer
                 {
                     if (ctx != IntPtr.Zero) return ctx;
                     NumericsProbe.Install();                          // before the first P/Invoke: picks the build that models this .NET's System.Numerics
-                    if (Native.swr_abi_version() != 2) throw new InvalidOperationException("libswr_hip.so: ABI version mismatch");
+                    if (Native.swr_abi_version() != 3) throw new InvalidOperationException("libswr_hip.so: ABI version mismatch");
                     int rc = Native.swr_create(0, out IntPtr c);       // one context drives one GPU; there is NO CPU fallback
                     if (rc != 0) throw new InvalidOperationException($"swr_create failed ({rc}): {Marshal.PtrToStringAnsi(Native.swr_last_error(IntPtr.Zero))}");
+                    NumericsProbe.Configure(c);                       // Transform / TransformNormal fused or not: run-time flags of the context
                     ctx = c;
                     return ctx;
                 }

@@ -33,8 +33,10 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 2     /* 2: swr_bind_framebuffer no longer drains (lifetime rule below); swr_resize / swr_set_band* are no-ops when
-                               * nothing changes; new: swr_sync_count, swr_build_info, swr_numerics_mode, swr_present_rgb_async / swr_present_wait */
+#define SWR_ABI_VERSION 3     /* 2: swr_bind_framebuffer no longer drains (lifetime rule below); swr_resize / swr_set_band* are no-ops when
+                               * nothing changes; new: swr_sync_count, swr_build_info, swr_numerics_mode, swr_present_rgb_async / swr_present_wait
+                               * 3: frames in flight (swr_set_pipelining / swr_get_pipelining, on by default); swr_set_transform_fma;
+                               *    one batch holds fewer than 2^26 vertex-stage records (see swr_render_mesh) */
 
 /* status codes */
 #define SWR_OK                 0
@@ -118,14 +120,21 @@ int  swr_abi_version(void);
  * pair the parity sweeps ran on is committed in profiles/verified_build.json and tests/test_gpu_api.py compares. */
 const char* swr_build_info(void);
 /* The System.Numerics model this library was compiled with (the reference's .NET 9 SIMD paths are not pinned by anything in
- * its repository): *fma = 1 when Vector4.Transform / Lerp are modelled with fused multiply-adds
- * (SWR_NUMERICS_FMA), *dot_order = summation order of Vector3.Dot / LengthSquared (SWR_DOT_PAIRWISE: 0 sequential, 1 dpps,
- * 2 shuffle-adds).  csharp/RasterizerNative.cs probes the running .NET at start-up and loads the library that matches. */
+ * its repository): *fma = 1 when Vector4.Lerp (Shaders.cs:52-55, Renderer.cs:858) is modelled with fused
+ * multiply-adds (SWR_NUMERICS_FMA), *dot_order = summation order of Vector3.Dot / LengthSquared (SWR_DOT_PAIRWISE: 0 sequential,
+ * 1 dpps, 2 shuffle-adds).  csharp/RasterizerNative.cs probes the running .NET at start-up and loads the library that matches. */
 int  swr_numerics_mode(int* fma, int* dot_order);
 const char* swr_last_error(const swr_context* ctx);   /* ctx may be NULL: last swr_create failure */
 
 /* lifetime -------------------------------------------------------------------------------- */
 int  swr_create(int device_id, swr_context** out);
+/* The other half of the System.Numerics model, per context and at run time (it only touches the vertex stage and the frustum
+ * test): whether Vector4.Transform / Vector3.Transform / Matrix4x4.Multiply (Renderer.cs:832-834, FrustumCuller.cs:203,213) and
+ * Vector3.TransformNormal (Renderer.cs:835) fuse their multiply-adds.  Default: both = the library's compile-time *fma.  Draws
+ * recorded before the call keep the model they were recorded under.  The C# start-up probe sets it from what it observes, so
+ * every (Transform, TransformNormal, Lerp, Dot) combination a .NET runtime can show is served by one of the six libraries. */
+int  swr_set_transform_fma(swr_context* ctx, int transform_fused, int transform_normal_fused);
+int  swr_get_transform_fma(swr_context* ctx, int* transform_fused, int* transform_normal_fused);
 void swr_destroy(swr_context* ctx);
 
 /* framebuffer == MainWindow.ColorBuffer / DepthBuffer (MainWindow.cs:25-31) ------------------ */
@@ -241,6 +250,13 @@ int  swr_render_mesh_culled(swr_context* ctx, const swr_mesh* mesh,
                             int cull_mode, int depth_test, int blend_mode);
 int  swr_flush(swr_context* ctx);    /* execute recorded draws (asynchronous on the stream) */
 int  swr_sync(swr_context* ctx);     /* flush + wait for the stream */
+/* Frames in flight.  The reference's loop renders frames back to back (Renderer.cs:404-419: RenderScene per frame; Rasterizer.cs:
+ * 163-230: RenderMesh per mesh).  With pipelining on (the default) the front end of flush N+1 -- vertex stage, clip, setup, binning,
+ * coverage -- runs on a second stream beside the raster kernel of flush N (double-buffered intermediates, event-ordered hand-over);
+ * pixels, counters and every ordering guarantee against the context's stream are unchanged.  mode: 0 = off (one stream, the
+ * configuration kernel timings are quoted on), 1 = on, 2 = on with the front stream at default priority (A/B).  Switching drains. */
+int  swr_set_pipelining(swr_context* ctx, int mode);
+int  swr_get_pipelining(swr_context* ctx, int* mode);
 
 /* Rasterizer.Interpolate (public, Rasterizer.cs:566-640), batched on the GPU for API coverage:
  * verts = 3 vertex records of 20 floats {clip4,color4,uv2,normal3,screen2,worldNormal3,pad2};
@@ -255,6 +271,9 @@ int  swr_profile_enable(swr_context* ctx, int on);       /* 0 off; 1 hipEvent pa
                                                            * 3 around the raster kernel of every 4th flush (a pair costs about 10 us of stream time) */
 int  swr_profile_get(swr_context* ctx, swr_profile* out); /* syncs */
 int  swr_profile_reset(swr_context* ctx);
+/* the duration (ms) of every raster-kernel launch that carried an event pair since swr_profile_reset, in launch order: *n = how
+ * many there are (at most 65,536 are kept), the first min(*n, capacity) are copied (bench.py: median / min / max).  syncs */
+int  swr_profile_raster_samples(swr_context* ctx, float* out_ms, int capacity, int* n);
 int  swr_device_name(swr_context* ctx, char* buf, int buflen);
 /* Self-test of the kernels' exact-division shortcut (csrc/swr_device.h: div_core / rcp_refined / sqrt_core): about
  * `samples` random, near-midpoint, boundary and renderer-shaped operand pairs are divided both ways on the GPU and compared bit

@@ -37,7 +37,8 @@ _libs = {}
 
 
 VARIANTS = {"": "liboswr.so", "fma": "liboswr_fma.so", "dotpw": "liboswr_dotpw.so", "fma_dotpw": "liboswr_fma_dotpw.so",
-            "dpps": "liboswr_dpps.so"}      # System.Numerics sensitivity builds (oracle/Makefile)
+            "dpps": "liboswr_dpps.so", "fma_dpps": "liboswr_fma_dpps.so",      # System.Numerics sensitivity builds (oracle/Makefile)
+            "deadcount": "liboswr_deadcount.so"}      # tools/dead_fragments.py builds it (-DOSWR_DEAD_COUNT); not a checker
 
 
 def load(fma: bool = False, variant: str = None) -> C.CDLL:
@@ -76,6 +77,8 @@ def load(fma: bool = False, variant: str = None) -> C.CDLL:
     lib.oswr_edge_function.restype = F; lib.oswr_edge_function.argtypes = [P, P, P]
     lib.oswr_numerics_fma.restype = I; lib.oswr_numerics_fma.argtypes = []
     lib.oswr_dot_pairwise.restype = I; lib.oswr_dot_pairwise.argtypes = []
+    lib.oswr_set_transform_fma.restype = None; lib.oswr_set_transform_fma.argtypes = [I, I]
+    lib.oswr_get_transform_fma.restype = None; lib.oswr_get_transform_fma.argtypes = [C.POINTER(I), C.POINTER(I)]
     lib.oswr_bounding_sphere.restype = None; lib.oswr_bounding_sphere.argtypes = [P, I, P]
     lib.oswr_is_sphere_in_frustum.restype = I; lib.oswr_is_sphere_in_frustum.argtypes = [P, P, P, P]
     _libs[name] = lib
@@ -89,8 +92,13 @@ def _f32(a):
 class OracleRenderer:
     """Renders a softwarerenderer_amd.scenes.Scene (or its draws one by one) on the CPU oracle."""
 
-    def __init__(self, width: int, height: int, threads: int = 1, fma: bool = False, variant: str = None):
+    def __init__(self, width: int, height: int, threads: int = 1, fma: bool = False, variant: str = None, transform_fma=None):
+        """transform_fma = (Transform fused?, TransformNormal fused?): the run-time half of the System.Numerics model (one setting per
+        library instance, re-applied before every draw of this renderer); None = the library's compile-time default for both"""
         self.lib = load(fma, variant)
+        d = bool(self.lib.oswr_numerics_fma())
+        self.transform_fma = (d, d) if transform_fma is None else (bool(transform_fma[0]), bool(transform_fma[1]))
+        self.lib.oswr_set_transform_fma(*[int(x) for x in self.transform_fma])
         self.ctx = self.lib.oswr_create(int(width), int(height))
         if not self.ctx:
             raise MemoryError("oswr_create failed")
@@ -137,6 +145,7 @@ class OracleRenderer:
 
     def render_mesh(self, vertices, indices, model, view, projection, program, uniforms=None, texture=None,
                     cull=1, depth_test=2, blend=1) -> int:
+        self.lib.oswr_set_transform_fma(*[int(x) for x in self.transform_fma])      # (per library instance: another renderer may have set it)
         v = np.ascontiguousarray(vertices)
         i = np.ascontiguousarray(indices, dtype=np.uint16).reshape(-1)
         m, vw, p = _f32(model), _f32(view), _f32(projection)

@@ -77,13 +77,20 @@ static inline int imin(int a, int b) { return a < b ? a : b; }
 static inline int is_nan_or_inf(float f) { return (f != f) || f == INFINITY || f == -INFINITY; }
 
 /* ---------- System.Numerics restatement (see header for the semantics assumed) ---------- */
-static inline float nm_madd(float a, float b, float c) {
-#if SWR_NUMERICS_FMA
-    return fmaf(a, b, c);
-#else
+/* Two families, modelled separately (nothing says .NET 9 treats them alike): Lerp is a compile-time switch (SWR_NUMERICS_FMA,
+ * like the HIP side, where it sits in the hot kernels); Transform / TransformNormal are run-time switches of this library
+ * instance (oswr_set_transform_fma; default = SWR_NUMERICS_FMA for both), mirroring swr_set_transform_fma. */
+static int g_transform_fma = SWR_NUMERICS_FMA, g_transform_normal_fma = SWR_NUMERICS_FMA;
+void oswr_set_transform_fma(int transform_fused, int transform_normal_fused) {
+    g_transform_fma = transform_fused != 0; g_transform_normal_fma = transform_normal_fused != 0;
+}
+void oswr_get_transform_fma(int* transform_fused, int* transform_normal_fused) {
+    *transform_fused = g_transform_fma; *transform_normal_fused = g_transform_normal_fma;
+}
+static inline float nm_madd(float a, float b, float c, int fused) {
+    if (fused) return fmaf(a, b, c);      /* (libm's correctly rounded fmaf when the build has no -mfma) */
     float p = a * b;
     return p + c;
-#endif
 }
 int oswr_numerics_fma(void) { return SWR_NUMERICS_FMA; }
 
@@ -91,9 +98,9 @@ int oswr_numerics_fma(void) { return SWR_NUMERICS_FMA; }
 static void vec4_transform(const float v[4], const float m[16], float out[4]) {
     for (int j = 0; j < 4; ++j) {
         float r = m[0 + j] * v[0];
-        r = nm_madd(m[4 + j], v[1], r);
-        r = nm_madd(m[8 + j], v[2], r);
-        r = nm_madd(m[12 + j], v[3], r);
+        r = nm_madd(m[4 + j], v[1], r, g_transform_fma);
+        r = nm_madd(m[8 + j], v[2], r, g_transform_fma);
+        r = nm_madd(m[12 + j], v[3], r, g_transform_fma);
         out[j] = r;
     }
 }
@@ -101,8 +108,8 @@ static void vec4_transform(const float v[4], const float m[16], float out[4]) {
 static void vec3_transform_normal(const float n[3], const float m[16], float out[3]) {
     for (int j = 0; j < 3; ++j) {
         float r = m[0 + j] * n[0];
-        r = nm_madd(m[4 + j], n[1], r);
-        r = nm_madd(m[8 + j], n[2], r);
+        r = nm_madd(m[4 + j], n[1], r, g_transform_normal_fma);
+        r = nm_madd(m[8 + j], n[2], r, g_transform_normal_fma);
         out[j] = r;
     }
 }
@@ -142,6 +149,7 @@ static inline float nm_lerp(float a, float b, float t) {
  * probe of csharp/RasterizerNative.cs evaluates Vector4.Transform / Vector4.Lerp / Vector3.Dot on operands chosen (by
  * tools/make_numerics_probe.py, from these functions in every build of this file) so that the models give different bits. */
 void oswr_nm_transform4(const float v[4], const float m[16], float out[4]) { vec4_transform(v, m, out); }
+void oswr_nm_transform_normal3(const float n[3], const float m[16], float out[3]) { vec3_transform_normal(n, m, out); }
 float oswr_nm_lerp(float a, float b, float t) { return nm_lerp(a, b, t); }
 float oswr_nm_dot3(const float a[3], const float b[3]) { return vec3_dot(a, b); }
 
@@ -509,6 +517,28 @@ static inline void tile_unlock(draw_state* ds, int idx) {
     if (ds->threaded) pthread_mutex_unlock(&ds->ctx->tile_locks[idx]);
 }
 
+#ifdef OSWR_DEAD_COUNT
+/* tools/dead_fragments.py only (a build of its own, never the checker the tests load): how many written fragments are later made
+ * irrelevant, bit for bit, by a written fragment of the same pixel whose alpha is exactly 1.0f under BlendMode.Alpha
+ * (Rasterizer.cs:58-65: src * 1 + dst * 0 == src when dst is finite and no component of src is a zero whose sign dst * 0 could flip) */
+static unsigned* dc_pending; static int dc_w, dc_h;
+unsigned long long oswr_dc_written, oswr_dc_dead, oswr_dc_alpha_one, oswr_dc_killers;
+void oswr_dead_count_reset(void) { free(dc_pending); dc_pending = NULL; oswr_dc_written = oswr_dc_dead = oswr_dc_alpha_one = oswr_dc_killers = 0; }
+static void oswr_dead_count_note(oswr_context* c, int x, int y, const float src[4], const float dst[4]) {
+    if (!dc_pending || dc_w != c->width || dc_h != c->height) {
+        free(dc_pending); dc_w = c->width; dc_h = c->height;
+        dc_pending = (unsigned*)calloc((size_t)dc_w * (size_t)dc_h, sizeof(unsigned));
+    }
+    unsigned* pend = &dc_pending[(size_t)y * (size_t)dc_w + (size_t)x];
+    ++oswr_dc_written;
+    if (src[3] == 1.0f) ++oswr_dc_alpha_one;
+    int finite = 1, nonzero = 1;
+    for (int i = 0; i < 4; ++i) { if (is_nan_or_inf(dst[i]) || is_nan_or_inf(src[i])) finite = 0; if (src[i] == 0.0f) nonzero = 0; }
+    if (src[3] == 1.0f && finite && nonzero) { oswr_dc_dead += *pend; *pend = 0; ++oswr_dc_killers; }
+    ++*pend;
+}
+#endif
+
 /* fragment tail shared by RasterizeTriangle and DrawLine; alpha_rule: 0 => W > 0 (:511), 1 => W != 0 (:325)
  * returns 1 if the pixel was written */
 static int shade_and_write(draw_state* ds, int x, int y, float depth, const oswr_vertex_output* frag, int alpha_rule) {
@@ -519,6 +549,9 @@ static int shade_and_write(draw_state* ds, int x, int y, float depth, const oswr
     if (!ok) return 0;
     float dst[4], out[4];
     fb_get_pixel(c, x, y, dst);
+#ifdef OSWR_DEAD_COUNT
+    oswr_dead_count_note(c, x, y, col, dst);
+#endif
     oswr_blend(col, dst, ds->blend, out);
     fb_set_pixel(c, x, y, out);
     if (ds->depth_test != OSWR_DEPTH_DISABLED) fb_set_depth(c, x, y, depth);

@@ -143,6 +143,11 @@ int   oswr_numerics_fma(void);
 int   oswr_dot_pairwise(void);   /* SWR_DOT_PAIRWISE of this build: 0 sequential, 1 dpps order, 2 two shuffle-adds */
 /* Vector4.Transform / VectorN.Lerp / Vector3.Dot as THIS build models them (numerics start-up probe, tools/make_numerics_probe.py) */
 void  oswr_nm_transform4(const float v[4], const float m[16], float out[4]);
+void  oswr_nm_transform_normal3(const float n[3], const float m[16], float out[3]);
+/* run-time half of the model: do Vector4.Transform (+ Vector3.Transform, Matrix4x4.Multiply) / Vector3.TransformNormal fuse their
+ * multiply-adds?  Per library instance; default = oswr_numerics_fma() for both (mirrors swr_set_transform_fma of include/swr.h) */
+void  oswr_set_transform_fma(int transform_fused, int transform_normal_fused);
+void  oswr_get_transform_fma(int* transform_fused, int* transform_normal_fused);
 float oswr_nm_lerp(float a, float b, float t);
 float oswr_nm_dot3(const float a[3], const float b[3]);
 

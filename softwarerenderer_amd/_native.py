@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ.get("SWR_LIB", "") or "libswr_hip.so"))
 
 SWR_OK = 0
-SWR_ABI_EXPECTED = 2
+SWR_ABI_EXPECTED = 3
 SWR_ERR_INVALID_ARG = -1
 SWR_ERR_HIP = -2
 SWR_ERR_OOM = -3
@@ -64,13 +64,13 @@ class Profile(C.Structure):
 
 # every symbol include/swr.h declares; tests/test_abi.py checks the library exports all of them
 EXPORTS = [
-    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved",
+    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_set_transform_fma", "swr_get_transform_fma", "swr_set_pipelining", "swr_get_pipelining", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved",
     "swr_bind_framebuffer", "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel",
     "swr_set_pixel", "swr_get_depth", "swr_set_depth", "swr_readback", "swr_readback_rgb", "swr_present_rgb_async", "swr_present_wait", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_sync_count", "swr_host_register", "swr_host_unregister", "swr_upload", "swr_color_device_ptr",
     "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter", "swr_texture_sample",
     "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync", "swr_interpolate", "swr_get_stats", "swr_reset_stats",
-    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_device_name", "swr_debug_counters", "swr_selftest_division",
+    "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_profile_raster_samples", "swr_device_name", "swr_debug_counters", "swr_selftest_division",
 ]
 
 _libs = {}
@@ -94,6 +94,10 @@ def load(name: str = None) -> C.CDLL:
         "swr_abi_version": (I, []),
         "swr_build_info": (C.c_char_p, []),
         "swr_numerics_mode": (I, [C.POINTER(I), C.POINTER(I)]),
+        "swr_set_transform_fma": (I, [P, I, I]),
+        "swr_get_transform_fma": (I, [P, C.POINTER(I), C.POINTER(I)]),
+        "swr_set_pipelining": (I, [P, I]),
+        "swr_get_pipelining": (I, [P, C.POINTER(I)]),
         "swr_last_error": (C.c_char_p, [P]),
         "swr_create": (I, [I, C.POINTER(P)]),
         "swr_destroy": (None, [P]),
@@ -142,6 +146,7 @@ def load(name: str = None) -> C.CDLL:
         "swr_profile_enable": (I, [P, I]),
         "swr_profile_get": (I, [P, C.POINTER(Profile)]),
         "swr_profile_reset": (I, [P]),
+        "swr_profile_raster_samples": (I, [P, fp, I, C.POINTER(I)]),
         "swr_device_name": (I, [P, C.c_char_p, I]),
         "swr_debug_counters": (I, [P, C.POINTER(C.c_uint64)]),
         "swr_selftest_division": (I, [P, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -5,6 +5,15 @@
 //     [k_frustum_cull ->] k_vertex -> k_setup -> k_bin<count> -> k_scan_sums/apply -> k_bin<fill> -> k_sort_tiles
 //     (+ the tile order in its last blocks) -> k_cover -> k_raster_c
 // There is no CPU fallback anywhere in this file: every pixel is produced by the HIP kernels.
+//
+// Frames in flight (swr_set_pipelining, on by default): the reference's loop renders frames back to back (Renderer.cs:404-419,
+// Rasterizer.cs:163-230), and a frame here has two halves with different bounds -- a front end of record traffic and latency
+// (vertex .. k_cover) and an issue-bound raster kernel.  The front end of flush N+1 therefore runs on a stream of its own
+// (`front_stream`) beside the raster kernel of flush N: everything a raster kernel reads lives in one of two RasterSets that
+// alternate per flush, two events per set order the hand-overs (front_done: F -> R, raster_done: R -> the front end that reuses
+// the set two flushes later), the tile order's history comes from flush N-1, and the poison / replay protocol is per batch
+// (batch_poisoned in swr_device.h).  The framebuffer is touched by the raster stream only, so everything a caller orders against
+// `stream` (flatten, read-back, collectives) still sees frames in submission order.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -60,6 +69,21 @@ struct EventSpan { int stage; hipEvent_t a, b; };
 #define SWR_SLOTS 3
 struct FrameSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
 
+// Everything of a batch that its raster kernel reads (or that a front-end kernel and the raster kernel share).  With frames
+// pipelined two sets alternate per flush, so the front end of flush N+1 never writes what the raster kernel of flush N reads;
+// with pipelining off only set 0 is used.  Buffers only the front end touches (slot_tb, want, tile_list, pair_tile, the scan's
+// totals) are single: front ends run in order on one stream.
+struct RasterSet {
+    DevBuf d_upload;         // draws | vertex block map | triangle block map [| bounds pointers | visibility words] of the batch
+    DevBuf d_vout, d_vnorm, d_recs;
+    DevBuf d_masks, d_pcounts, d_pair_refs;
+    DevBuf d_tile_count, d_tile_start;
+    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32, [tile_bucket n_tiles] u8: heaviest-first raster order
+    uint32_t hist_tiles = 0; // tile count the fragment history in d_order (tile_work) belongs to (0: none yet)
+    hipEvent_t front_done = nullptr, raster_done = nullptr;
+    bool raster_pending = false;      // raster_done has been recorded and the stream has not been drained since
+};
+
 struct DrawCmd {
     DrawParams p;
     swr_mesh* mesh;
@@ -85,6 +109,10 @@ struct swr_context {
     std::mutex mu;
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t front_stream = nullptr;    // front ends of pipelined flushes (and mesh uploads, which only front-end kernels read)
+    int pipelining = 1;                    // swr_set_pipelining: 0 off, 1 on (front stream at high priority), 2 on (normal priority: A/B)
+    int front_prio_mode = 0;               // pipelining mode the front stream was created for
+    RasterSet sets[2];
     uint32_t raster_span_no = 0;           // profiling mode 3: raster launches seen since swr_profile_enable
     char dev_name[256] = { 0 };
 
@@ -100,6 +128,7 @@ struct swr_context {
     DevBuf own_color, own_depth;
     void* ext_color = nullptr; void* ext_depth = nullptr;
 
+    uint32_t nm_flags = SWR_NUMERICS_FMA ? (SWR_NM_TRANSFORM_FMA | SWR_NM_TRANSFORM_NORMAL_FMA) : 0u;   // swr_set_transform_fma
     float near_clip = 0.1f, far_clip = 1000.0f;   // Rasterizer.cs:20-21
     int debug_mode = SWR_DEBUG_NONE;               // Rasterizer.cs:22
 
@@ -114,15 +143,13 @@ struct swr_context {
     bool sync_flush = false;                  // SWR_SYNC_FLUSH=1: read the pair total back in every flush
     uint32_t debug_fill_capacity = 0;         // SWR_DEBUG_FILL_CAPACITY=n: k_bin<FILL> of optimistic flushes sees a list of n entries (tests)
 
-    DevBuf d_vnorm;          // VertexOutput.Normal per VOut entry: allocated and written only for batches with a DEBUG_VARYINGS draw
-    DevBuf d_upload, d_vout, d_recs, d_slot_tb;   // d_upload = draws | vertex block map | triangle block map of the running batch
+    DevBuf d_slot_tb;        // (the vertex-stage output, the records and the upload block live in the RasterSets)
     FrameSlot slots[SWR_SLOTS];
     uint32_t slot_next = 0;
-    DevBuf d_pair_tile, d_masks, d_pcounts, d_pair_refs, d_ctrl;
+    DevBuf d_pair_tile, d_ctrl;
     uint32_t* host_poison = nullptr;           // pinned, device-visible copy of Ctrl::poison
-    DevBuf d_tile_count, d_tile_start, d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
+    DevBuf d_tile_list, d_tile_stats, d_counters, d_total, d_scratch;
     DevBuf d_want;           // 1 byte per slot: COUNT's pair_may_cover decisions, replayed by FILL
-    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32, [tile_bucket n_tiles] u8: heaviest-first raster order
     size_t tile_stats_tiles = 0;
     swr_stats totals = {};
     unsigned long long host_tile_pairs = 0;   // rounds sized on the host (MODE_SYNC)
@@ -139,6 +166,7 @@ struct swr_context {
 
     int profiling = 0;                         // 0 off, 1 every stage, 2 only the raster kernel (2 events per flush)
     std::vector<EventSpan> spans;
+    std::vector<float> raster_samples;         // duration of every raster launch that carried an event pair since swr_profile_reset (<= 65,536)
     std::vector<hipEvent_t> event_pool;
     swr_profile prof = {};
 };
@@ -260,15 +288,16 @@ hipEvent_t get_event(swr_context* c) {
 }
 struct ScopedSpan {
     swr_context* c; int stage; hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
     bool on = false;
-    ScopedSpan(swr_context* c_, int st) : c(c_), stage(st) {
+    ScopedSpan(swr_context* c_, int st, hipStream_t s_ = nullptr) : c(c_), stage(st), s(s_ ? s_ : c_->stream) {
         // 1: every stage; 2: the raster kernel of every flush; 3: the raster kernel of every 4th flush (an event pair costs
         // about 10 us of stream time: sampling keeps a timed region within 0.5 % of its unobserved rate)
         on = c->profiling == 1 || (st == ST_RASTER && (c->profiling == 2 || (c->profiling == 3 && (c->raster_span_no++ & 3u) == 0u)));
-        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if (on) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, s); }
     }
     ~ScopedSpan() {
-        if (on) { (void)hipEventRecord(b, c->stream); c->spans.push_back({ stage, a, b }); }
+        if (on) { (void)hipEventRecord(b, s); c->spans.push_back({ stage, a, b }); }
     }
 };
 
@@ -282,7 +311,9 @@ void collect_spans(swr_context* c) {      // stream must be idle
             case ST_BIN:    c->prof.bin_ms += ms; break;
             case ST_SORT:   c->prof.sort_ms += ms; break;
             case ST_COVER:  c->prof.cover_ms += ms; break;
-            case ST_RASTER: c->prof.raster_ms += ms; c->prof.raster_launches++; break;
+            case ST_RASTER: c->prof.raster_ms += ms; c->prof.raster_launches++;
+                            if (c->raster_samples.size() < 65536) c->raster_samples.push_back(ms);
+                            break;
             case ST_CLEAR:  c->prof.clear_ms += ms; break;
             }
             c->prof.total_ms += ms;
@@ -305,14 +336,44 @@ void free_garbage(swr_context* c) {       // stream must be idle
 int validate_locked(swr_context* c);
 int check_list_overflow(swr_context* c);
 
+// both streams idle (the raster stream waits for every front end it depends on; the front stream may carry mesh uploads beyond that)
+int drain_streams(swr_context* c) {
+    SWR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->front_stream) SWR_HIP(c, hipStreamSynchronize(c->front_stream));
+    for (auto& s : c->sets) s.raster_pending = false;
+    return SWR_OK;
+}
+
 int sync_locked(swr_context* c) {
     ++c->host_syncs;
-    SWR_HIP(c, hipStreamSynchronize(c->stream));
-    int rc = validate_locked(c);
+    int rc = drain_streams(c);
+    if (rc) return rc;
+    rc = validate_locked(c);
     collect_spans(c);
     free_garbage(c);
     for (auto& fs : c->slots) fs.busy = false;     // stream idle: every slot is free
     return rc;
+}
+
+// the stream mesh uploads and front-end-only work go to: the front stream while frames are pipelined, else the context's stream
+hipStream_t front_stream_of(swr_context* c) { return (c->pipelining && c->front_stream) ? c->front_stream : c->stream; }
+
+// (re)creates the front stream for the current pipelining mode; streams must be idle
+int ensure_front_stream(swr_context* c) {
+    if (!c->pipelining) return SWR_OK;
+    if (c->front_stream && c->front_prio_mode == c->pipelining) return SWR_OK;
+    if (c->front_stream) { SWR_HIP(c, hipStreamSynchronize(c->front_stream)); SWR_HIP(c, hipStreamDestroy(c->front_stream)); c->front_stream = nullptr; }
+    int least = 0, greatest = 0;
+    SWR_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    // mode 1: the front end's short kernels go first wherever a slot frees up, the raster kernel (65,536 one-wave workgroups) fills the rest
+    (void)least;
+    SWR_HIP(c, hipStreamCreateWithPriority(&c->front_stream, hipStreamNonBlocking, c->pipelining == 1 ? greatest : 0));      // 0 = the default priority
+    c->front_prio_mode = c->pipelining;
+    for (auto& s : c->sets) {
+        if (!s.front_done) SWR_HIP(c, hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
+        if (!s.raster_done) SWR_HIP(c, hipEventCreateWithFlags(&s.raster_done, hipEventDisableTiming));
+    }
+    return SWR_OK;
 }
 
 enum { MODE_SYNC = 0, MODE_ASYNC = 1 };
@@ -322,17 +383,26 @@ static bool b_has_debug_varyings(const Batch& b) {
 }
 const unsigned long long kMaxPairs = 1ull << 30;       // list entries per round (4 GiB of slot ids)
 
+// pairs every set in use can hold (the optimistic flush is checked against this on the device)
 size_t pair_capacity(const swr_context* c) {
-    return std::min(std::min(std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4), std::min(c->d_masks.cap / 32, c->d_pcounts.cap / 8)),
-                    c->d_pair_refs.cap / 16);
+    size_t cap = std::min(c->d_tile_list.cap / 4, c->d_pair_tile.cap / 4);
+    for (int i = 0; i < (c->pipelining ? 2 : 1); ++i) {
+        const RasterSet& s = c->sets[i];
+        cap = std::min(cap, std::min(std::min(s.d_masks.cap / 32, s.d_pcounts.cap / 8), s.d_pair_refs.cap / 16));
+    }
+    return cap;
 }
 int ensure_pairs(swr_context* c, size_t n) {
     int rc;
     if ((rc = ensure(c, c->d_tile_list, n * 4))) return rc;
     if ((rc = ensure(c, c->d_pair_tile, n * 4))) return rc;
-    if ((rc = ensure(c, c->d_masks, n * 32))) return rc;
-    if ((rc = ensure(c, c->d_pair_refs, n * 16))) return rc;
-    return ensure(c, c->d_pcounts, n * 8 + 64);
+    for (int i = 0; i < (c->pipelining ? 2 : 1); ++i) {
+        RasterSet& s = c->sets[i];
+        if ((rc = ensure(c, s.d_masks, n * 32))) return rc;
+        if ((rc = ensure(c, s.d_pair_refs, n * 16))) return rc;
+        if ((rc = ensure(c, s.d_pcounts, n * 8 + 64))) return rc;
+    }
+    return SWR_OK;
 }
 
 int run_clear(swr_context* c, const Batch& b, bool& cc, bool& cd, const float rgba_[4]) {
@@ -342,7 +412,7 @@ int run_clear(swr_context* c, const Batch& b, bool& cc, bool& cd, const float rg
         int blocks = (int)std::min<size_t>((n + 255) / 256, 2048 * 8);
         float4 rgba = make_float4(rgba_[0], rgba_[1], rgba_[2], rgba_[3]);
         hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, c->stream, b.color, b.depth, n, rgba,
-                           cc ? 1 : 0, cd ? 1 : 0, (const Ctrl*)c->d_ctrl.as<Ctrl>());
+                           cc ? 1 : 0, cd ? 1 : 0, (const Ctrl*)c->d_ctrl.as<Ctrl>(), b.seq);
         SWR_HIP(c, hipGetLastError());
     }
     cc = cd = false;
@@ -352,17 +422,17 @@ int run_clear(swr_context* c, const Batch& b, bool& cc, bool& cd, const float rg
 // bins slots [lo, hi) and rasterises them.  MODE_SYNC reads the pair total back (sizes buffers exactly, splits a
 // range that would need more than kMaxPairs entries); MODE_ASYNC launches everything against the current capacity.
 // the BinArgs of one round (slots [lo, hi) of batch b)
-static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32_t hi) {
+static BinArgs make_bin_args(swr_context* c, RasterSet& S, const Batch& b, uint32_t lo, uint32_t hi) {
     BinArgs ba;
     ba.slot_tb = c->d_slot_tb.as<unsigned long long>();
-    ba.recs = c->d_recs.as<TriRec>();
+    ba.recs = S.d_recs.as<TriRec>();
     ba.slot_lo = lo; ba.slot_hi = hi;
     ba.spt = b.wireframe ? 6u : 2u;
     ba.width = c->W; ba.height = c->H;
     ba.tiles_x = c->tiles_x; ba.band_ty0 = c->band_ty0; ba.band_ty1 = c->band_ty1;
     ba.band = host_band_map(c);
-    ba.tile_count = c->d_tile_count.as<uint32_t>();
-    ba.tile_start = c->d_tile_start.as<uint32_t>();
+    ba.tile_count = S.d_tile_count.as<uint32_t>();
+    ba.tile_start = S.d_tile_start.as<uint32_t>();
     ba.tile_list = c->d_tile_list.as<uint32_t>();
     ba.list_capacity = (uint32_t)std::min<size_t>(pair_capacity(c), 0xffffffffu);
     ba.counters = c->d_counters.as<Counters>();
@@ -375,36 +445,36 @@ static BinArgs make_bin_args(swr_context* c, const Batch& b, uint32_t lo, uint32
 }
 
 // counts_clear: k_vertex of this batch cleared the per-tile counters and the tile order's histogram (no memsets here)
-int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode, bool counts_clear = false) {
+int bin_and_raster(swr_context* c, RasterSet& S, hipStream_t F, const Batch& b, bool& cc, bool& cd, uint32_t lo, uint32_t hi, int mode, bool counts_clear = false) {
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     if (n_tiles == 0 || lo >= hi) return SWR_OK;
     int rc;
     const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
     unsigned long long* d_total = c->d_total.as<unsigned long long>();
-    uint32_t* tile_work = c->d_order.as<uint32_t>();
+    uint32_t* tile_work = S.d_order.as<uint32_t>();
     uint32_t* tile_order = tile_work + n_tiles;
     uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
     uint8_t* tile_bucket = reinterpret_cast<uint8_t*>(order_hist + 2 * SWR_ORDER_BUCKETS);     // [n_tiles]
-    BinArgs ba = make_bin_args(c, b, lo, hi);
+    BinArgs ba = make_bin_args(c, S, b, lo, hi);
     ba.replayable = mode == MODE_ASYNC ? 1u : 0u;
     const uint32_t bin_threads = (hi - lo + ba.spt - 1u) / ba.spt;          // = triangles
     ba.tpw = 64u;                                                            // aim for >= ~1000 waves
     while (ba.tpw > 4u && bin_threads < ba.tpw * 1024u) ba.tpw >>= 1;
     const uint32_t bin_blocks = (bin_threads + 4u * ba.tpw - 1u) / (4u * ba.tpw);
     {
-        ScopedSpan sp(c, ST_BIN);
+        ScopedSpan sp(c, ST_BIN, F);
         if (!counts_clear) {
-            SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, c->stream));
-            SWR_HIP(c, hipMemsetAsync(order_hist, 0, 2 * SWR_ORDER_BUCKETS * 4, c->stream));
+            SWR_HIP(c, hipMemsetAsync(ba.tile_count, 0, (size_t)n_tiles * 4, F));
+            SWR_HIP(c, hipMemsetAsync(order_hist, 0, 2 * SWR_ORDER_BUCKETS * 4, F));
         }
-        hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, c->stream, ba);
+        hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, F, ba);
         const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
         unsigned long long* sums = d_total + 32;      // room for 1024 block sums
-        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, c->stream, (const uint32_t*)ba.tile_count, n_tiles, sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, F, (const uint32_t*)ba.tile_count, n_tiles, sums);
         // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
         const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
-        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, c->stream, ba.tile_count,
-                           c->d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, F, ba.tile_count,
+                           S.d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
                            cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
                            mode == MODE_ASYNC ? 1 : 0, (const uint32_t*)tile_work, order_hist, tile_bucket);
         SWR_HIP(c, hipGetLastError());
@@ -412,15 +482,15 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
     uint32_t cover_items = ba.list_capacity;          // async: grid covers the whole capacity, lanes beyond the total exit
     if (mode == MODE_SYNC) {
         unsigned long long total = 0;
-        SWR_HIP(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-        SWR_HIP(c, hipStreamSynchronize(c->stream));
+        SWR_HIP(c, hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, F));      // (MODE_SYNC: F is the context's stream)
+        SWR_HIP(c, hipStreamSynchronize(F));
         if (total > kMaxPairs && hi - lo > 2) {
             // too many (triangle, tile) pairs for one round: split the slot range.  Order is preserved
             // because the framebuffer carries the state from one round to the next.
             uint32_t mid = lo + (((hi - lo) / 2u) & ~1u);
             if (mid == lo) mid = lo + 2;
-            if ((rc = bin_and_raster(c, b, cc, cd, lo, mid, mode))) return rc;
-            return bin_and_raster(c, b, cc, cd, mid, hi, mode);
+            if ((rc = bin_and_raster(c, S, F, b, cc, cd, lo, mid, mode))) return rc;
+            return bin_and_raster(c, S, F, b, cc, cd, mid, hi, mode);
         }
         Counters* tp = c->d_counters.as<Counters>() + 64;          // tile_pairs of a round that really runs
         if (total == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
@@ -433,7 +503,7 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         cover_items = (uint32_t)total;
     }
     {
-        ScopedSpan sp(c, ST_BIN);
+        ScopedSpan sp(c, ST_BIN, F);
         BinArgs bf = ba;
         // test hook: a FILL capacity below what COUNT was checked against forces the list-overflow path (bin_overflow)
         if (mode == MODE_ASYNC && c->debug_fill_capacity) bf.list_capacity = std::min(bf.list_capacity, c->debug_fill_capacity);
@@ -441,49 +511,54 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         bf.bin_blocks = bin_blocks;
         bf.order_tiles_y = c->band_tile_rows;
         bf.tile_bucket = tile_bucket; bf.order_hist = order_hist; bf.order_cursor = order_hist + SWR_ORDER_BUCKETS; bf.tile_order = tile_order;
-        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks + order_blocks(c->tiles_x, c->band_tile_rows)), dim3(256), 0, c->stream, bf);   // cursors were zeroed by k_scan_apply
+        hipLaunchKernelGGL(k_bin<true>, dim3(bin_blocks + order_blocks(c->tiles_x, c->band_tile_rows)), dim3(256), 0, F, bf);   // cursors were zeroed by k_scan_apply
         SWR_HIP(c, hipGetLastError());
     }
     {
-        ScopedSpan sp(c, ST_SORT);
-        hipLaunchKernelGGL(k_sort_tiles, dim3((n_tiles + SWR_SORT_TPB * SWR_SORT_TPW - 1u) / (SWR_SORT_TPB * SWR_SORT_TPW)), dim3(64 * SWR_SORT_TPB), 0, c->stream, c->d_tile_start.as<uint32_t>(),
-                           c->d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl,
+        ScopedSpan sp(c, ST_SORT, F);
+        hipLaunchKernelGGL(k_sort_tiles, dim3((n_tiles + SWR_SORT_TPB * SWR_SORT_TPW - 1u) / (SWR_SORT_TPB * SWR_SORT_TPW)), dim3(64 * SWR_SORT_TPB), 0, F, S.d_tile_start.as<uint32_t>(),
+                           S.d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl, b.seq,
                            (const uint32_t*)tile_order);
         SWR_HIP(c, hipGetLastError());
     }
     if (cover_items) {
-        ScopedSpan sp(c, ST_COVER);
+        ScopedSpan sp(c, ST_COVER, F);
         CoverArgs ca;
-        ca.recs = c->d_recs.as<TriRec>();
+        ca.recs = S.d_recs.as<TriRec>();
         ca.tile_list = c->d_tile_list.as<uint32_t>();
         ca.pair_tile = c->d_pair_tile.as<uint32_t>();
-        ca.masks = c->d_masks.as<uint4>();
-        ca.info = c->d_pcounts.as<uint2>();
-        ca.refs = c->d_pair_refs.as<uint4>();
+        ca.masks = S.d_masks.as<uint4>();
+        ca.info = S.d_pcounts.as<uint2>();
+        ca.refs = S.d_pair_refs.as<uint4>();
         ca.n_pairs = d_total;
-        ca.ctrl = ctrl;
+        ca.ctrl = ctrl; ca.seq = b.seq;
         ca.fp = frame_params(c);
         ca.fp.near_clip = b.near_clip;
         ca.dbg = d_total + 8;
         // (a multiple of 8 blocks: the kernel hands XCD x the x-th contiguous eighth of the blocks that hold pairs)
         const dim3 cg((unsigned)((((cover_items + (uint32_t)SWR_COVER_BLOCK - 1u) / (uint32_t)SWR_COVER_BLOCK) + 7u) & ~7u)), cb(SWR_COVER_BLOCK);
-        if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, cg, cb, 0, c->stream, ca);
-        else hipLaunchKernelGGL(k_cover<false>, cg, cb, 0, c->stream, ca);
+        if (b.wireframe) hipLaunchKernelGGL(k_cover<true>, cg, cb, 0, F, ca);
+        else hipLaunchKernelGGL(k_cover<false>, cg, cb, 0, F, ca);
         SWR_HIP(c, hipGetLastError());
+    }
+    if (F != c->stream) {
+        // hand-over: the raster kernel (context's stream) starts when this batch's front end is complete
+        SWR_HIP(c, hipEventRecord(S.front_done, F));
+        SWR_HIP(c, hipStreamWaitEvent(c->stream, S.front_done, 0));
     }
     {
         ScopedSpan sp(c, ST_RASTER);
         RasterArgs ra;
         ra.fp = frame_params(c);
         ra.fp.near_clip = b.near_clip;
-        ra.recs = c->d_recs.as<TriRec>();
-        ra.vout = c->d_vout.as<VOut>();
-        ra.vout_bytes = (uint32_t)std::min<size_t>(c->d_vout.cap, 0xfffffff0u);
-        ra.vnorm = b_has_debug_varyings(b) ? c->d_vnorm.as<float4>() : nullptr;
-        ra.draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
-        ra.tile_start = c->d_tile_start.as<uint32_t>();
-        ra.tile_count = c->d_tile_count.as<uint32_t>();
-        ra.pair_refs = c->d_pair_refs.as<uint4>();
+        ra.recs = S.d_recs.as<TriRec>();
+        ra.vout = S.d_vout.as<VOut>();
+        ra.vout_bytes = (uint32_t)std::min<size_t>(S.d_vout.cap, 0xfffffff0u);
+        ra.vnorm = b_has_debug_varyings(b) ? S.d_vnorm.as<float4>() : nullptr;
+        ra.draws = reinterpret_cast<const DrawParams*>(S.d_upload.p);
+        ra.tile_start = S.d_tile_start.as<uint32_t>();
+        ra.tile_count = S.d_tile_count.as<uint32_t>();
+        ra.pair_refs = S.d_pair_refs.as<uint4>();
         ra.color = b.color; ra.depth = b.depth;
         ra.tile_stats = c->d_tile_stats.as<uint32_t>();
         memcpy(ra.clear_rgba, b.clear_rgba, 16);
@@ -493,11 +568,11 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         ra.tile_work = tile_work;
         ra.n_tiles = n_tiles;
         ra.dbg = d_total + 8;     // zero unless a SWR_DEBUG_COUNTERS build bumps it
-        ra.ctrl = ctrl;
+        ra.ctrl = ctrl; ra.seq = b.seq;
         {
             const dim3 g((n_tiles + 511u) & ~511u), t(64);       // one wave per tile (grid in whole 8 x 64 XCD segments)
-            const uint4* mk = (const uint4*)c->d_masks.as<uint4>();
-            const uint2* pc = (const uint2*)c->d_pcounts.as<uint2>();
+            const uint4* mk = (const uint4*)S.d_masks.as<uint4>();
+            const uint2* pc = (const uint2*)S.d_pcounts.as<uint2>();
             bool phong = false, none = false, dust2_default = true, grows = true, phong_default = true, gouraud_default = true;
             for (auto& d : b.draws) {
                 gouraud_default = gouraud_default && d.p.program == SWR_PROG_GOURAUD &&
@@ -530,6 +605,11 @@ int bin_and_raster(swr_context* c, const Batch& b, bool& cc, bool& cd, uint32_t 
         SWR_HIP(c, hipGetLastError());
         cc = cd = false;
     }
+    if (c->pipelining && S.raster_done) {
+        // ... and the front end that reuses this set (two flushes from now) starts when this raster kernel is complete
+        SWR_HIP(c, hipEventRecord(S.raster_done, c->stream));
+        S.raster_pending = true;
+    }
     return SWR_OK;
 }
 
@@ -538,6 +618,13 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     bool cc = b.clear_color, cd = b.clear_depth;
     if (b.draws.empty()) return run_clear(c, b, cc, cd, b.clear_rgba);
     int rc;
+    // pipelined flushes alternate between the two RasterSets and run their front end on the front stream; a synchronous batch (the
+    // first frame, a replay, SWR_SYNC_FLUSH) reads the pair total back half way and runs on the context's stream alone
+    if ((rc = ensure_front_stream(c))) return rc;
+    const bool piped = mode == MODE_ASYNC && c->pipelining != 0;
+    RasterSet& S = c->sets[c->pipelining ? (b.seq & 1u) : 0u];
+    const hipStream_t F = piped ? c->front_stream : c->stream;
+    if (c->pipelining && !piped) SWR_HIP(c, hipStreamSynchronize(c->front_stream));     // earlier front ends and mesh uploads
     const size_t nd = b.draws.size();
     std::vector<DrawParams> hp(nd);
     std::vector<BlockMap> vblocks, tblocks;
@@ -578,16 +665,16 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const size_t off_bp = (off_tb + tblocks.size() * sizeof(BlockMap) + 255) & ~(size_t)255;     // per-draw bounds pointers
     const size_t off_vis = (off_bp + (any_cull ? nd * sizeof(void*) : 0) + 255) & ~(size_t)255;   // per-draw visibility words
     const size_t up_bytes = off_vis + (any_cull ? nd * 4 : 0);
-    if ((rc = ensure(c, c->d_upload, up_bytes))) return rc;
-    if ((rc = ensure(c, c->d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
+    if ((rc = ensure(c, S.d_upload, up_bytes))) return rc;
+    if ((rc = ensure(c, S.d_vout, (size_t)(V + 4 * T) * sizeof(VOut)))) return rc;
     const bool dbgv = b_has_debug_varyings(b);
-    if (dbgv && (rc = ensure(c, c->d_vnorm, c->d_vout.cap / 4))) return rc;        // one float4 per VOut entry
-    if ((rc = ensure(c, c->d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
+    if (dbgv && (rc = ensure(c, S.d_vnorm, S.d_vout.cap / 4))) return rc;        // one float4 per VOut entry
+    if ((rc = ensure(c, S.d_recs, (size_t)(spt * T) * sizeof(TriRec)))) return rc;
     if ((rc = ensure(c, c->d_slot_tb, (size_t)(spt * T) * 8))) return rc;
     if ((rc = ensure(c, c->d_want, (size_t)(spt * T) + 64))) return rc;
-    if ((rc = ensure(c, c->d_tile_count, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, c->d_tile_start, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, c->d_order, (size_t)n_tiles * 9 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
+    if ((rc = ensure(c, S.d_tile_count, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, S.d_tile_start, (size_t)n_tiles * 4))) return rc;
+    if ((rc = ensure(c, S.d_order, (size_t)n_tiles * 9 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
         // another tile count (resize / band change): the fragment counters gathered so far move into the carry words of d_total
         // (swr_get_stats adds them), in stream order, so totals survive a change of geometry
@@ -598,8 +685,13 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         }
         if ((rc = ensure(c, c->d_tile_stats, (size_t)n_tiles * 12))) return rc;
         SWR_HIP(c, hipMemsetAsync(c->d_tile_stats.p, 0, (size_t)n_tiles * 12, c->stream));
-        SWR_HIP(c, hipMemsetAsync(c->d_order.p, 0, (size_t)n_tiles * 4, c->stream));      // no fragment history for the new tiling
         c->tile_stats_tiles = n_tiles;
+    }
+    // the set's buffers were last read by the raster kernel of two flushes ago
+    if (piped && S.raster_pending) SWR_HIP(c, hipStreamWaitEvent(F, S.raster_done, 0));
+    if (S.hist_tiles != n_tiles) {
+        SWR_HIP(c, hipMemsetAsync(S.d_order.p, 0, (size_t)n_tiles * 4, F));      // no fragment history for this tiling in this set
+        S.hist_tiles = n_tiles;
     }
     char* stage = (char*)slot_acquire(c, up_bytes);
     if (!stage) return fail(c, SWR_ERR_OOM, "hipHostMalloc failed for the upload staging block");
@@ -610,45 +702,48 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         const float4** bp = reinterpret_cast<const float4**>(stage + off_bp);
         for (size_t i = 0; i < nd; ++i) bp[i] = b.draws[i].frustum_cull ? b.draws[i].mesh->d_bounds : nullptr;
     }
-    SWR_HIP(c, hipMemcpyAsync(c->d_upload.p, stage, up_bytes, hipMemcpyHostToDevice, c->stream));
-    const DrawParams* d_draws = reinterpret_cast<const DrawParams*>(c->d_upload.p);
-    const BlockMap* d_vblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_vb);
-    const BlockMap* d_tblocks = reinterpret_cast<const BlockMap*>((char*)c->d_upload.p + off_tb);
+    SWR_HIP(c, hipMemcpyAsync(S.d_upload.p, stage, up_bytes, hipMemcpyHostToDevice, F));
+    const DrawParams* d_draws = reinterpret_cast<const DrawParams*>(S.d_upload.p);
+    const BlockMap* d_vblocks = reinterpret_cast<const BlockMap*>((char*)S.d_upload.p + off_vb);
+    const BlockMap* d_tblocks = reinterpret_cast<const BlockMap*>((char*)S.d_upload.p + off_tb);
 
     const uint32_t* d_visible = nullptr;
     if (any_cull) {
-        ScopedSpan sp(c, ST_VERTEX);
-        uint32_t* vis = reinterpret_cast<uint32_t*>((char*)c->d_upload.p + off_vis);
-        hipLaunchKernelGGL(k_frustum_cull, dim3((unsigned)((nd + 63) / 64)), dim3(64), 0, c->stream, d_draws,
-                           reinterpret_cast<const float4* const*>((char*)c->d_upload.p + off_bp), (uint32_t)nd, vis);
+        ScopedSpan sp(c, ST_VERTEX, F);
+        uint32_t* vis = reinterpret_cast<uint32_t*>((char*)S.d_upload.p + off_vis);
+        hipLaunchKernelGGL(k_frustum_cull, dim3((unsigned)((nd + 63) / 64)), dim3(64), 0, F, d_draws,
+                           reinterpret_cast<const float4* const*>((char*)S.d_upload.p + off_bp), (uint32_t)nd, vis);
         SWR_HIP(c, hipGetLastError());
         d_visible = vis;
     }
     FrameParams fp = frame_params(c);
     fp.near_clip = b.near_clip;
     if (!vblocks.empty()) {
-        ScopedSpan sp(c, ST_VERTEX);
-        hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, c->stream,
-                           d_draws, d_vblocks, c->d_vout.as<VOut>(), d_visible,
-                           reinterpret_cast<float*>((char*)c->d_upload.p + offsetof(DrawParams, fog_r1)),
-                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr, c->d_tile_count.as<uint32_t>(), n_tiles,
-                           c->d_order.as<uint32_t>() + 2 * (size_t)n_tiles);
+        ScopedSpan sp(c, ST_VERTEX, F);
+        hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, F,
+                           d_draws, d_vblocks, S.d_vout.as<VOut>(), d_visible,
+                           reinterpret_cast<float*>((char*)S.d_upload.p + offsetof(DrawParams, fog_r1)),
+                           dbgv ? S.d_vnorm.as<float4>() : (float4*)nullptr, S.d_tile_count.as<uint32_t>(), n_tiles,
+                           S.d_order.as<uint32_t>() + 2 * (size_t)n_tiles);
         SWR_HIP(c, hipGetLastError());
     }
     const bool counts_clear = !vblocks.empty() && n_tiles != 0;      // k_vertex cleared the per-tile counters and the order histogram
     {
-        ScopedSpan sp(c, ST_SETUP);
-        hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, c->stream,
-                           d_draws, d_tblocks, (const VOut*)c->d_vout.as<VOut>(),
-                           c->d_vout.as<VOut>() + V, (uint32_t)V, c->d_recs.as<TriRec>(),
+        ScopedSpan sp(c, ST_SETUP, F);
+        hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, F,
+                           d_draws, d_tblocks, (const VOut*)S.d_vout.as<VOut>(),
+                           S.d_vout.as<VOut>() + V, (uint32_t)V, S.d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
-                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), count_stats, b.wireframe ? 1 : 0, d_visible,
-                           dbgv ? c->d_vnorm.as<float4>() : (float4*)nullptr);
+                           (const Ctrl*)c->d_ctrl.as<Ctrl>(), b.seq, count_stats, b.wireframe ? 1 : 0, d_visible,
+                           dbgv ? S.d_vnorm.as<float4>() : (float4*)nullptr);
         SWR_HIP(c, hipGetLastError());
     }
-    rc = bin_and_raster(c, b, cc, cd, 0, (uint32_t)(spt * T), mode, counts_clear);
+    rc = bin_and_raster(c, S, F, b, cc, cd, 0, (uint32_t)(spt * T), mode, counts_clear);
     slot_submit(c);
     if (rc) return rc;
+    // a synchronous batch ran its front end on the context's stream: the next pipelined front end shares slot_tb / want / the lists
+    // with it, so it may not start before this one is over (rare path: the first frame and replays)
+    if (c->pipelining && !piped) SWR_HIP(c, hipStreamSynchronize(c->stream));
     if (cc || cd) return run_clear(c, b, cc, cd, b.clear_rgba);   // nothing was binned
     return SWR_OK;
 }
@@ -687,7 +782,7 @@ int validate_locked(swr_context* c) {
                 rc = execute_batch(c, b, MODE_SYNC, b.seq != h.first_bad);   // the first bad batch already counted its triangles
             retire_batch(c, b);
         }
-        if (!rc) { hipError_t e = hipStreamSynchronize(c->stream); if (e != hipSuccess) { c->err = hipGetErrorString(e); rc = SWR_ERR_HIP; } }
+        if (!rc) rc = drain_streams(c);
         if (!rc) rc = check_list_overflow(c);
         return rc;
     }
@@ -728,7 +823,7 @@ int flush_locked(swr_context* c) {
     if (optimistic && !rc) {
         c->inflight.push_back(std::move(b));
         if (c->inflight.size() >= 64) {                            // bound the replay log
-            SWR_HIP(c, hipStreamSynchronize(c->stream));
+            if ((rc = drain_streams(c))) return rc;
             rc = validate_locked(c);
         }
     } else {
@@ -740,7 +835,8 @@ int flush_locked(swr_context* c) {
 int ensure_bounds(swr_context* c, swr_mesh* m) {
     if (m->bounds_ready) return SWR_OK;
     if (!m->d_bounds) SWR_HIP(c, hipMalloc((void**)&m->d_bounds, sizeof(float4)));
-    hipLaunchKernelGGL(k_bounding_sphere, dim3(1), dim3(1024), 0, c->stream, (const swr_vertex*)m->d_verts, (uint32_t)m->n_verts, m->d_bounds);
+    // (on the stream the mesh was uploaded on and k_frustum_cull will read the result on)
+    hipLaunchKernelGGL(k_bounding_sphere, dim3(1), dim3(1024), 0, front_stream_of(c), (const swr_vertex*)m->d_verts, (uint32_t)m->n_verts, m->d_bounds);
     SWR_HIP(c, hipGetLastError());
     m->bounds_ready = true;
     return SWR_OK;
@@ -836,6 +932,7 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     d.p.tex_wf = tex ? (float)tex->w : 0.0f; d.p.tex_hf = tex ? (float)tex->h : 0.0f;
     d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
     d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
+    d.p.nm_flags = c->nm_flags;
     d.mesh = mesh;
     d.frustum_cull = frustum_cull;
     if (frustum_cull) { int rc = ensure_bounds(c, mesh); if (rc) return rc; }
@@ -865,8 +962,9 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
     hipError_t e = hipSuccess;
     if (nv) e = hipMalloc((void**)&m->d_verts, (size_t)nv * sizeof(swr_vertex));
     if (e == hipSuccess && ni) e = hipMalloc((void**)&m->d_idx, (size_t)ni * 2 + 8);
-    if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, c->stream);
+    // (only front-end kernels read a mesh: the upload goes to their stream, so a pipelined frame does not wait for the raster stream)
+    if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, front_stream_of(c));
+    if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, front_stream_of(c));
     if (e != hipSuccess) {
         if (m->d_verts) (void)hipFree(m->d_verts);
         if (m->d_idx) (void)hipFree(m->d_idx);
@@ -907,6 +1005,22 @@ int swr_numerics_mode(int* fma, int* dot_order) {
     return SWR_OK;
 }
 
+int swr_set_transform_fma(swr_context* c, int transform_fused, int transform_normal_fused) {
+    if (!c) return SWR_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock_(c->mu);
+    // (draws recorded so far keep the model they were recorded under: DrawParams::nm_flags)
+    c->nm_flags = (transform_fused ? SWR_NM_TRANSFORM_FMA : 0u) | (transform_normal_fused ? SWR_NM_TRANSFORM_NORMAL_FMA : 0u);
+    return SWR_OK;
+}
+
+int swr_get_transform_fma(swr_context* c, int* transform_fused, int* transform_normal_fused) {
+    if (!c || !transform_fused || !transform_normal_fused) return SWR_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock_(c->mu);
+    *transform_fused = (c->nm_flags & SWR_NM_TRANSFORM_FMA) ? 1 : 0;
+    *transform_normal_fused = (c->nm_flags & SWR_NM_TRANSFORM_NORMAL_FMA) ? 1 : 0;
+    return SWR_OK;
+}
+
 const char* swr_last_error(const swr_context* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int swr_create(int device_id, swr_context** out) {
@@ -933,6 +1047,7 @@ int swr_create(int device_id, swr_context** out) {
         g_create_error = hipGetErrorString(e); delete c; return SWR_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (ensure_front_stream(c)) { g_create_error = c->err; (void)hipStreamDestroy(c->own_stream); delete c; return SWR_ERR_HIP; }
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
     { const char* df = getenv("SWR_DEBUG_FILL_CAPACITY"); c->debug_fill_capacity = df ? (uint32_t)strtoul(df, nullptr, 10) : 0u; }
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
@@ -951,6 +1066,7 @@ void swr_destroy(swr_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->front_stream) (void)hipStreamSynchronize(c->front_stream);
     for (auto& d : c->draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
     for (auto& b : c->inflight) retire_batch(c, b);
     c->inflight.clear();
@@ -965,10 +1081,16 @@ void swr_destroy(swr_context* c) {
         if (c->present_done[i]) (void)hipEventDestroy(c->present_done[i]);
         release(c->present_buf[i]);
     }
-    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_upload, &c->d_vout, &c->d_vnorm, &c->d_recs,
-                       &c->d_slot_tb, &c->d_want, &c->d_ctrl, &c->d_pair_tile, &c->d_masks, &c->d_pcounts, &c->d_pair_refs, &c->d_tile_count, &c->d_tile_start, &c->d_tile_list, &c->d_tile_stats, &c->d_order,
+    DevBuf* bufs[] = { &c->own_color, &c->own_depth, &c->d_slot_tb, &c->d_want, &c->d_ctrl, &c->d_pair_tile, &c->d_tile_list, &c->d_tile_stats,
                        &c->d_counters, &c->d_total, &c->d_scratch };
     for (DevBuf* b : bufs) release(*b);
+    for (auto& s : c->sets) {
+        DevBuf* sb[] = { &s.d_upload, &s.d_vout, &s.d_vnorm, &s.d_recs, &s.d_masks, &s.d_pcounts, &s.d_pair_refs, &s.d_tile_count, &s.d_tile_start, &s.d_order };
+        for (DevBuf* b : sb) release(*b);
+        if (s.front_done) (void)hipEventDestroy(s.front_done);
+        if (s.raster_done) (void)hipEventDestroy(s.raster_done);
+    }
+    if (c->front_stream) (void)hipStreamDestroy(c->front_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1059,6 +1181,24 @@ int swr_clear_depth(swr_context* c) {
 }
 
 int swr_flush(swr_context* c) { SWR_ENTER(c); return flush_locked(c); }
+
+int swr_set_pipelining(swr_context* c, int mode) {
+    SWR_ENTER(c);
+    if (mode < 0 || mode > 2) return fail(c, SWR_ERR_INVALID_ARG, "pipelining mode must be 0 (off), 1 (on) or 2 (on, front stream at normal priority)");
+    if (mode == c->pipelining) return SWR_OK;
+    int rc = flush_locked(c);
+    if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;          // nothing in flight while the streams and the set in use change
+    c->pipelining = mode;
+    return ensure_front_stream(c);
+}
+
+int swr_get_pipelining(swr_context* c, int* mode) {
+    SWR_ENTER(c);
+    if (!mode) return SWR_ERR_INVALID_ARG;
+    *mode = c->pipelining;
+    return SWR_OK;
+}
 
 int swr_sync(swr_context* c) {
     SWR_ENTER(c);
@@ -1370,8 +1510,8 @@ int swr_mesh_bounds(swr_context* c, const swr_mesh* mesh, float center_radius[4]
     if (!mesh || !center_radius) return fail(c, SWR_ERR_INVALID_ARG, "bad mesh_bounds arguments");
     int rc = ensure_bounds(c, const_cast<swr_mesh*>(mesh));
     if (rc) return rc;
-    SWR_HIP(c, hipMemcpyAsync(center_radius, mesh->d_bounds, 16, hipMemcpyDeviceToHost, c->stream));
-    SWR_HIP(c, hipStreamSynchronize(c->stream));
+    SWR_HIP(c, hipMemcpyAsync(center_radius, mesh->d_bounds, 16, hipMemcpyDeviceToHost, front_stream_of(c)));
+    SWR_HIP(c, hipStreamSynchronize(front_stream_of(c)));
     return SWR_OK;
 }
 
@@ -1387,7 +1527,7 @@ int swr_is_sphere_in_frustum(swr_context* c, const float center_radius[4], const
     SWR_HIP(c, hipMemcpyAsync(base, h, sizeof h, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_frustum_test, dim3(1), dim3(64), 0, c->stream,
                        make_float4(center_radius[0], center_radius[1], center_radius[2], center_radius[3]),
-                       (const float*)base, (uint32_t*)(base + 192));
+                       (const float*)base, (uint32_t*)(base + 192), c->nm_flags);
     SWR_HIP(c, hipGetLastError());
     uint32_t r = 0;
     SWR_HIP(c, hipMemcpyAsync(&r, base + 192, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1489,6 +1629,17 @@ int swr_profile_reset(swr_context* c) {
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
     c->prof = {};
+    c->raster_samples.clear();
+    return SWR_OK;
+}
+int swr_profile_raster_samples(swr_context* c, float* out_ms, int capacity, int* n) {
+    SWR_ENTER(c);
+    if (!n || capacity < 0 || (capacity > 0 && !out_ms)) return SWR_ERR_INVALID_ARG;
+    int rc = flush_locked(c); if (rc) return rc;
+    if ((rc = sync_locked(c))) return rc;
+    const int have = (int)c->raster_samples.size();
+    for (int i = 0; i < std::min(have, capacity); ++i) out_ms[i] = c->raster_samples[(size_t)i];
+    *n = have;
     return SWR_OK;
 }
 

@@ -388,7 +388,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
-    if (FILL && a.ctrl->poison) return;
+    if (FILL && batch_poisoned(a.ctrl, a.seq)) return;
     if (FILL && blockIdx.x >= a.bin_blocks) {                   // the grid's last blocks: the raster kernel's tile order
         static_assert(SWR_BIN_TABLE >= SWR_ORDER_BUCKETS, "tile_place_block borrows the hash table's LDS");
         tile_place_block(a, blockIdx.x - a.bin_blocks, s_key, s_val);
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
             atomicMax(&ctrl->need, total);
             __hip_atomic_store(&ctrl->poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (ctrl->host_flag) __hip_atomic_store(ctrl->host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (poison_on_overflow && !ctrl->poison) {
+        } else if (poison_on_overflow && !batch_poisoned(ctrl, seq)) {
             atomicAdd(&counters->tile_pairs, total);        // MODE_SYNC rounds are counted by the host
         }
     }
@@ -602,11 +602,11 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
 __global__ __launch_bounds__(64 * SWR_SORT_TPB) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_list, uint32_t n_tiles,
-                                                   uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl,
+                                                   uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl, uint32_t seq,
                                                    const uint32_t* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
                                                        pairs sort for 10+ us in one wave and must not start last */) {
     __shared__ uint32_t s_keys_all[SWR_SORT_TPB][SWR_SORT_LDS];
-    if (ctrl->poison) return;
+    if (batch_poisoned(ctrl, seq)) return;
     static_assert(SWR_SORT_TPW <= 64, "one lane per tile of the wave fetches its count and start");
     const uint32_t first = (blockIdx.x * SWR_SORT_TPB + (threadIdx.x >> 6)) * SWR_SORT_TPW;
     const uint32_t lane = threadIdx.x & 63u;

@@ -94,10 +94,11 @@ __global__ __launch_bounds__(1024) void k_bounding_sphere(const swr_vertex* __re
 
 // IsSphereInFrustum, FrustumCuller.cs:201-224 (planes tested in the reference's order Left, Right, Top, Bottom, Near, Far)
 __device__ __forceinline__ bool sphere_in_frustum(float4 sphere, const float* __restrict__ model, const float* __restrict__ view,
-                                                  const float* __restrict__ proj) {
+                                                  const float* __restrict__ proj, uint32_t nm_flags) {
+    const bool fma_t = (nm_flags & SWR_NM_TRANSFORM_FMA) != 0u;           // Vector3.Transform and Matrix4x4.Multiply: the Transform family
     const float c4[4] = { sphere.x, sphere.y, sphere.z, 1.0f };
     float wc[4];
-    vec4_transform(c4, model, wc);                                                       // Vector3.Transform(center, model)
+    vec4_transform(c4, model, wc, fma_t);                                                // Vector3.Transform(center, model)
     const float s0 = sqrtf((model[0] * model[0] + model[1] * model[1]) + model[2] * model[2]);    // :204-209
     const float s1 = sqrtf((model[4] * model[4] + model[5] * model[5]) + model[6] * model[6]);
     const float s2 = sqrtf((model[8] * model[8] + model[9] * model[9]) + model[10] * model[10]);
@@ -106,7 +107,7 @@ __device__ __forceinline__ bool sphere_in_frustum(float4 sphere, const float* __
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float row[4] = { view[4 * i], view[4 * i + 1], view[4 * i + 2], view[4 * i + 3] };
-        vec4_transform(row, proj, vp + 4 * i);
+        vec4_transform(row, proj, vp + 4 * i, fma_t);
     }
     bool inside = true;
 #pragma unroll
@@ -131,11 +132,11 @@ __global__ __launch_bounds__(64) void k_frustum_cull(const DrawParams* __restric
     const uint32_t d = blockIdx.x * 64u + threadIdx.x;
     if (d >= n_draws) return;
     const float4* b = bounds[d];
-    visible[d] = b ? (sphere_in_frustum(*b, draws[d].model, draws[d].view, draws[d].proj) ? 1u : 0u) : 1u;
+    visible[d] = b ? (sphere_in_frustum(*b, draws[d].model, draws[d].view, draws[d].proj, draws[d].nm_flags) ? 1u : 0u) : 1u;
 }
 
-__global__ void k_frustum_test(float4 sphere, const float* __restrict__ mvp48, uint32_t* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *out = sphere_in_frustum(sphere, mvp48, mvp48 + 16, mvp48 + 32) ? 1u : 0u;
+__global__ void k_frustum_test(float4 sphere, const float* __restrict__ mvp48, uint32_t* __restrict__ out, uint32_t nm_flags) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = sphere_in_frustum(sphere, mvp48, mvp48 + 16, mvp48 + 32, nm_flags) ? 1u : 0u;
 }
 
 }  // namespace swr

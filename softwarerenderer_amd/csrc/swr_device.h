@@ -10,9 +10,19 @@
 #include <stdint.h>
 #include "swr.h"
 
+// System.Numerics models.  Whether .NET 9 fuses the multiply-adds of Vector4.Transform / Vector3.TransformNormal /
+// Matrix4x4.Multiply and of Vector4.Lerp cannot be settled here, and nothing says the answer is the same for both families:
+//   * Lerp (Shaders.Lerp in the clipper, Renderer.cs:858 in the fragment stage) sits in the hot kernels: COMPILE-TIME, SWR_NUMERICS_FMA;
+//   * Transform / TransformNormal live in the vertex stage and the frustum test only: RUN-TIME flags per context
+//     (swr_set_transform_fma -> DrawParams::nm_flags), whose default is SWR_NUMERICS_FMA for both, so libswr_hip_fma.so alone still
+//     models "everything fused".
+// With the three dot orders (SWR_DOT_PAIRWISE) that is six libraries x four flag settings: every combination the C# start-up probe
+// can observe is served.
 #ifndef SWR_NUMERICS_FMA
-#define SWR_NUMERICS_FMA 0   // 1 models a fused MultiplyAddEstimate inside System.Numerics Transform/Lerp
+#define SWR_NUMERICS_FMA 0   // 1 models a fused MultiplyAddEstimate inside System.Numerics Lerp (and is the default of the run-time Transform flags)
 #endif
+#define SWR_NM_TRANSFORM_FMA        1u    // DrawParams::nm_flags: Vector4.Transform / Vector3.Transform / Matrix4x4.Multiply fuse
+#define SWR_NM_TRANSFORM_NORMAL_FMA 2u    // Vector3.TransformNormal fuses
 #ifndef SWR_DOT_PAIRWISE
 #define SWR_DOT_PAIRWISE 0   // summation order of Vector3.Dot / LengthSquared (Renderer.cs:835,851, Rasterizer.cs:684) on the
 #endif                       // (x, y, z, 0) lanes of a Vector128: 0 sequential (xx + yy) + zz; 1 dpps order (xx + yy) + (zz + 0);
@@ -78,7 +88,7 @@ struct DrawParams {
                             // uniforms) equals this draw's (execute_batch): k_setup writes it into TriRec::draw_flags instead of the
                             // draw's own index, so k_raster_c -- which cuts a fragment chunk where the draw changes, because the
                             // per-draw constants are wave-uniform -- sees the 16 meshes of one model with one material as ONE draw
-    uint32_t pad_;
+    uint32_t nm_flags;      // SWR_NM_*: the context's System.Numerics model of Transform / TransformNormal when the draw was recorded
 };
 static_assert(offsetof(DrawParams, fog_den) == offsetof(DrawParams, fog_r1) + 12, "k_vertex writes fog_den three floats after fog_r1");
 
@@ -92,8 +102,8 @@ struct Counters {           // device-side swr_stats accumulators
 
 // Optimistic execution control block (one per context, in HBM).  A flush is launched without reading the pair
 // total back: k_scan_apply compares it with the list capacity and, if it does not fit, sets `poison`; every
-// kernel that would touch the pair lists or the framebuffer returns at once while `poison` is set (also for later
-// batches), so the framebuffer stays exactly as it was before the first batch that did not fit.  The host looks
+// kernel of that batch and of every later one that would touch the pair lists or the framebuffer returns at once
+// (batch_poisoned), so the framebuffer stays exactly as it was before the first batch that did not fit.  The host looks
 // at this block at its next synchronisation point, grows the buffers and replays from `first_bad`.
 struct Ctrl {
     uint32_t poison;
@@ -101,6 +111,11 @@ struct Ctrl {
     unsigned long long need;         // largest pair total seen by a batch that did not fit (atomicMax)
     uint32_t* host_flag;             // pinned host word, set to 1 together with `poison`: the host polls it without a copy
 };
+// Must batch `seq` leave the pair lists and the framebuffer alone?  Yes when it, or a batch before it, did not fit.  Decided by
+// `first_bad`, not by the sticky `poison` word: with frames pipelined (swr_api.hip: the front end of flush N+1 runs beside the
+// raster kernel of flush N) a LATER batch may poison itself while this one's raster kernel is half way through its tiles, and
+// that must not stop the tiles that have not started yet -- the host replays from `first_bad` only.
+__device__ __forceinline__ bool batch_poisoned(const Ctrl* __restrict__ c, uint32_t seq) { return c->first_bad <= seq; }
 
 struct FrameParams {
     int width, height;          // full frame
@@ -228,33 +243,40 @@ __device__ __forceinline__ float sqrt_core(float x) {
 }
 
 // ---------------------------------------------------------------- System.Numerics ----
+template <bool FUSED>
 __device__ __forceinline__ float nm_madd(float a, float b, float c) {
-#if SWR_NUMERICS_FMA
-    return __builtin_fmaf(a, b, c);
-#else
+    if (FUSED) return __builtin_fmaf(a, b, c);
     float p = a * b;
     return p + c;
-#endif
 }
 // Vector4.Transform(v, M): ((x*row1 + y*row2) + z*row3) + w*row4 ; M row-major M11..M44
-__device__ __forceinline__ void vec4_transform(const float v[4], const float* __restrict__ m, float out[4]) {
+template <bool FUSED>
+__device__ __forceinline__ void vec4_transform_t(const float v[4], const float* __restrict__ m, float out[4]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float r = m[j] * v[0];
-        r = nm_madd(m[4 + j], v[1], r);
-        r = nm_madd(m[8 + j], v[2], r);
-        r = nm_madd(m[12 + j], v[3], r);
+        r = nm_madd<FUSED>(m[4 + j], v[1], r);
+        r = nm_madd<FUSED>(m[8 + j], v[2], r);
+        r = nm_madd<FUSED>(m[12 + j], v[3], r);
         out[j] = r;
     }
 }
-__device__ __forceinline__ void vec3_transform_normal(const float n[3], const float* __restrict__ m, float out[3]) {
+template <bool FUSED>
+__device__ __forceinline__ void vec3_transform_normal_t(const float n[3], const float* __restrict__ m, float out[3]) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         float r = m[j] * n[0];
-        r = nm_madd(m[4 + j], n[1], r);
-        r = nm_madd(m[8 + j], n[2], r);
+        r = nm_madd<FUSED>(m[4 + j], n[1], r);
+        r = nm_madd<FUSED>(m[8 + j], n[2], r);
         out[j] = r;
     }
+}
+// `fused` is uniform over a draw (DrawParams::nm_flags): one scalar branch per call site
+__device__ __forceinline__ void vec4_transform(const float v[4], const float* __restrict__ m, float out[4], bool fused) {
+    if (fused) vec4_transform_t<true>(v, m, out); else vec4_transform_t<false>(v, m, out);
+}
+__device__ __forceinline__ void vec3_transform_normal(const float n[3], const float* __restrict__ m, float out[3], bool fused) {
+    if (fused) vec3_transform_normal_t<true>(n, m, out); else vec3_transform_normal_t<false>(n, m, out);
 }
 __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz) {
 #if SWR_DOT_PAIRWISE == 1

@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
 
     float p[4] = { q0.x, q0.y, q0.z, 1.0f };
     float world[4], viewp[4], clip[4];
-    vec4_transform(p, dp->model, world);        // Renderer.cs:832
-    vec4_transform(world, dp->view, viewp);     // :833
-    vec4_transform(viewp, dp->proj, clip);      // :834
+    const bool fma_t = (dp->nm_flags & SWR_NM_TRANSFORM_FMA) != 0u, fma_tn = (dp->nm_flags & SWR_NM_TRANSFORM_NORMAL_FMA) != 0u;
+    vec4_transform(p, dp->model, world, fma_t);        // Renderer.cs:832
+    vec4_transform(world, dp->view, viewp, fma_t);     // :833
+    vec4_transform(viewp, dp->proj, clip, fma_t);      // :834
     float n[3] = { q1.y, q1.z, q1.w }, tn[3];
-    vec3_transform_normal(n, dp->model, tn);    // :835
+    vec3_transform_normal(n, dp->model, tn, fma_tn);   // :835
     float len = sqrtf(dot3(tn[0], tn[1], tn[2], tn[0], tn[1], tn[2]));   // Vector3.Normalize = v / Length()
 
 #ifdef SWR_VERTEX_DIRECT_STORES
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
                                                unsigned long long* __restrict__ slot_tb,
                                                FrameParams fp,
                                                Counters* __restrict__ counters /* 64 replicas */,
-                                               const Ctrl* __restrict__ ctrl, int count_stats, int wireframe,
+                                               const Ctrl* __restrict__ ctrl, uint32_t seq, int count_stats, int wireframe,
                                                const uint32_t* __restrict__ visible,
                                                float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */) {
     const BlockMap bm = blocks[blockIdx.x];
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
         atomicAdd(&s_cnt[2], (unsigned)__popcll(clip_mask));
     }
     __syncthreads();
-    if (threadIdx.x == 0 && count_stats && !ctrl->poison) {
+    if (threadIdx.x == 0 && count_stats && !batch_poisoned(ctrl, seq)) {
         Counters* c = counters + (blockIdx.x & 63);
         atomicAdd(&c->triangles_in, (unsigned long long)s_cnt[0]);
         if (s_cnt[1]) atomicAdd(&c->triangles_setup, (unsigned long long)s_cnt[1]);

@@ -30,7 +30,8 @@ struct RasterArgs {
     int clear_color_on, clear_depth_on;
     int depth_only_grows;                  // every draw of the batch tests Less or LessEqual (enables hi-Z in the generic kernels)
     unsigned long long* dbg;               // SWR_DEBUG_COUNTERS builds only: 8 accumulators
-    const Ctrl* __restrict__ ctrl;         // poison guard (see Ctrl)
+    const Ctrl* __restrict__ ctrl;         // poison guard (see Ctrl, batch_poisoned)
+    uint32_t seq;                          // sequence number of the batch
 };
 
 // fragment inputs a built-in program may read
@@ -342,8 +343,8 @@ __device__ __forceinline__ float4 shade_debug_varyings(float w0f, float w1f, flo
 
 // ---- small utility kernels -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_clear(float4* __restrict__ color, float* __restrict__ depth, size_t n,
-                                               float4 rgba, int do_color, int do_depth, const Ctrl* __restrict__ ctrl) {
-    if (ctrl->poison) return;
+                                               float4 rgba, int do_color, int do_depth, const Ctrl* __restrict__ ctrl, uint32_t seq) {
+    if (batch_poisoned(ctrl, seq)) return;
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
         if (do_color) color[i] = rgba;
         if (do_depth) depth[i] = SWR_FLOAT_MINVALUE;

@@ -109,6 +109,7 @@ struct CoverArgs {
                                               // then needs no load that depends on another load
     const unsigned long long* __restrict__ n_pairs;   // device-resident pair total of this batch
     const Ctrl* __restrict__ ctrl;
+    uint32_t seq;                             // sequence number of the batch (batch_poisoned)
     FrameParams fp;
     unsigned long long* dbg;                  // SWR_DEBUG_COVER builds only (tools/debug_counters.py)
 };
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     __shared__ uint32_t s_hmax[CB / 64];
     if (threadIdx.x < CB / 64) s_hmax[threadIdx.x] = 0u;
 #endif
-    if (a.ctrl->poison) return;
+    if (batch_poisoned(a.ctrl, a.seq)) return;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
     // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own, and a triangle's pairs sit in neighbouring tiles: the one to
     // the right a few dozen pairs away, the one below a whole tile row (thousands of pairs) away.  XCD x therefore takes the x-th
@@ -535,7 +536,7 @@ template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bo
 __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG)) ? 5 : SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
-    if (a.ctrl->poison) return;
+    if (batch_poisoned(a.ctrl, a.seq)) return;
 
     const int lane = threadIdx.x & 63;
     // hi-Z needs every draw of the batch to use Less / LessEqual (stored depth only grows): compile-time state, or the host's word

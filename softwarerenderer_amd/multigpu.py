@@ -84,7 +84,7 @@ def max_band_rows(height: int, world_size: int) -> int:
 
 
 def gather_bands(local_band, height: int, width: int, rank: int, world_size: int, dst: int = 0, group=None, frame=None, dist=None,
-                 async_op: bool = False, post_stream=None):
+                 async_op: bool = False, post_stream=None, force_collective: bool = False):
     """Gather the per-rank colour bands (torch tensors of shape (max_band_rows, width, C), rows beyond a
     band's own count are padding) to `dst`; returns the assembled (height, width, C) frame there, else None.
     `frame` (optional, dst only) is a preallocated output.  When every band has the same number of pixel rows
@@ -96,7 +96,7 @@ def gather_bands(local_band, height: int, width: int, rank: int, world_size: int
     import torch
     if dist is None:
         import torch.distributed as dist
-    if world_size == 1:
+    if world_size == 1 and not force_collective:         # (force_collective: bench.py --force-dist runs the RCCL leg with one rank)
         out = local_band[:band_pixel_rows(height, (0, tile_rows(height)))[1]]
         return (out, None) if async_op else out
     bands = band_partition(height, world_size)

@@ -153,6 +153,14 @@ class Device:
         self._ck(self._lib.swr_profile_get(self._ctx, C.byref(p)))
         return {n: (float(getattr(p, n)) if t is C.c_double else int(getattr(p, n))) for n, t in N.Profile._fields_}
 
+    def raster_samples(self) -> np.ndarray:
+        """Duration (ms) of every raster-kernel launch that carried an event pair since profile_reset (swr_profile_raster_samples)."""
+        n = C.c_int(0)
+        self._ck(self._lib.swr_profile_raster_samples(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros(max(int(n.value), 1), dtype=np.float32)
+        self._ck(self._lib.swr_profile_raster_samples(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), int(out.size), C.byref(n)))
+        return out[:int(n.value)]
+
     def profile_reset(self):
         self._ck(self._lib.swr_profile_reset(self._ctx))
 
@@ -183,6 +191,26 @@ class Device:
         f, d = C.c_int(0), C.c_int(0)
         self._ck(self._lib.swr_numerics_mode(C.byref(f), C.byref(d)))
         return int(f.value), int(d.value)
+
+    def set_transform_fma(self, transform_fused: bool, transform_normal_fused: bool):
+        """The run-time half of the System.Numerics model (swr_set_transform_fma): do Vector4.Transform (Renderer.cs:832-834) /
+        Vector3.TransformNormal (:835) fuse their multiply-adds?  Default = the library's compile-time fma for both."""
+        self._ck(self._lib.swr_set_transform_fma(self._ctx, int(bool(transform_fused)), int(bool(transform_normal_fused))))
+
+    def transform_fma(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self._ck(self._lib.swr_get_transform_fma(self._ctx, C.byref(a), C.byref(b)))
+        return bool(a.value), bool(b.value)
+
+    def set_pipelining(self, mode: int):
+        """swr_set_pipelining: 0 = one stream (kernel timings are quoted on this), 1 = the front end of flush N+1 beside the raster
+        kernel of flush N (default), 2 = the same with the front stream at default priority."""
+        self._ck(self._lib.swr_set_pipelining(self._ctx, int(mode)))
+
+    def pipelining(self) -> int:
+        m = C.c_int(0)
+        self._ck(self._lib.swr_get_pipelining(self._ctx, C.byref(m)))
+        return int(m.value)
 
     def set_stream(self, hip_stream: int):
         self._ck(self._lib.swr_set_stream(self._ctx, C.c_void_p(hip_stream)))

@@ -356,6 +356,25 @@ class SceneRenderer:
             Rasterizer.RenderMesh(w, mesh if mesh is not None else d.vertices, d.indices, d.model, d.view, d.projection,
                                   prog.VertexShader, prog.FragmentShader, d.cull, d.depth_test, d.blend)
 
+    def jitter_views(self, frame_no: int, amplitude: float):
+        """Host-side camera motion for benchmarks (bench.py --camera-jitter): frame `frame_no` sees every draw's view matrix followed
+        by a small yaw and a translation of `amplitude` view-space units, different each frame (amplitude 0 restores the scene's own
+        matrices).  Only the float arrays the prepared RenderMesh calls point at change: nothing is re-uploaded."""
+        if self._calls is None:
+            self._calls = self._prepare() or False
+        if not self._calls:
+            raise RuntimeError("jitter_views needs retained meshes")
+        if not hasattr(self, "_base_views"):
+            self._base_views = [mats[1].copy() for mats, _ in self._calls]
+        a = float(amplitude)
+        k = float(frame_no)
+        yaw = 0.02 * a * np.sin(0.9 * k + 0.3)
+        t = np.eye(4, dtype=np.float64)
+        t[0, 0] = np.cos(yaw); t[0, 2] = -np.sin(yaw); t[2, 0] = np.sin(yaw); t[2, 2] = np.cos(yaw)       # row-vector convention
+        t[3, 0] = a * np.sin(0.7 * k); t[3, 1] = a * np.cos(1.3 * k + 0.5); t[3, 2] = 0.5 * a * np.sin(0.31 * k)
+        for (mats, _), base in zip(self._calls, self._base_views):
+            mats[1][:] = (base.reshape(4, 4).astype(np.float64) @ t).astype(np.float32).reshape(-1) if a != 0.0 else base
+
     def render(self):
         self.submit_frame()
         return self.window._read(True, True)

@@ -13,13 +13,13 @@
 #define RESOLVE(name) do { *(void**)(&p_##name) = dlsym(lib, #name); if (!p_##name) { fprintf(stderr, "missing symbol %s\n", #name); return 2; } } while (0)
 
 static const char* const all_symbols[] = {
-    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_sync_count", "swr_present_rgb_async", "swr_present_wait", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved", "swr_bind_framebuffer",
+    "swr_abi_version", "swr_build_info", "swr_numerics_mode", "swr_set_transform_fma", "swr_get_transform_fma", "swr_set_pipelining", "swr_get_pipelining", "swr_sync_count", "swr_present_rgb_async", "swr_present_wait", "swr_last_error", "swr_create", "swr_destroy", "swr_resize", "swr_set_band", "swr_set_band_interleaved", "swr_bind_framebuffer",
     "swr_set_stream", "swr_clear_color", "swr_clear_depth", "swr_get_pixel", "swr_set_pixel", "swr_get_depth", "swr_set_depth",
     "swr_readback", "swr_readback_rgb", "swr_flatten_rgb_device", "swr_flatten_rgb_device_async", "swr_replay_count", "swr_host_register", "swr_host_unregister", "swr_upload",
     "swr_color_device_ptr", "swr_depth_device_ptr", "swr_texture_create", "swr_texture_destroy", "swr_texture_set_filter",
     "swr_texture_sample", "swr_mesh_create", "swr_mesh_destroy", "swr_set_state", "swr_initialize_tile_locks", "swr_render_mesh",
     "swr_render_mesh_arrays", "swr_mesh_bounds", "swr_is_sphere_in_frustum", "swr_render_mesh_culled", "swr_flush", "swr_sync",
-    "swr_interpolate", "swr_get_stats", "swr_reset_stats", "swr_profile_enable", "swr_profile_get", "swr_profile_reset",
+    "swr_interpolate", "swr_get_stats", "swr_reset_stats", "swr_profile_enable", "swr_profile_get", "swr_profile_reset", "swr_profile_raster_samples",
     "swr_device_name", "swr_debug_counters", "swr_selftest_division" };
 
 int main(int argc, char** argv) {

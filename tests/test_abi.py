@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     missing = [f for f in header_functions() if not hasattr(lib, f)]
     assert not missing, missing
     lib.swr_abi_version.restype = ctypes.c_int
-    assert lib.swr_abi_version() == 2
+    assert lib.swr_abi_version() == 3
 
 
 def test_struct_layouts_match_the_reference_types():
@@ -167,49 +167,68 @@ def _probe_models():
     return mod, mod.models()
 
 
-def _observe(mod, lib, probes):
-    """What NumericsProbe.Observe() computes, with ONE oracle build standing in for the running System.Numerics."""
+def _observe(mod, lib, probes, transform_fused, transform_normal_fused):
+    """What NumericsProbe.Observe() computes, with ONE oracle build (its Lerp and Dot) and one setting of its run-time Transform
+    flags standing in for the running System.Numerics."""
     import struct
     f = lambda b: struct.unpack("<f", struct.pack("<I", b))[0]
     p = probes
-    return {"lerp": mod.lerp(lib, f(p["lerp"]["a"]), f(p["lerp"]["b"]), f(p["lerp"]["t"])),
-            "transform": mod.transform_x(lib, [f(x) for x in p["transform"]["v"]], [f(x) for x in p["transform"]["column"]]),
-            "dot": mod.dot(lib, [f(x) for x in p["dot"]["a"]], [f(x) for x in p["dot"]["b"]]),
-            "dot_zero": mod.dot(lib, [f(x) for x in p["dot_zero"]["a"]], [f(x) for x in p["dot_zero"]["b"]])}
+    obs = {"lerp": mod.lerp(lib, f(p["lerp"]["a"]), f(p["lerp"]["b"]), f(p["lerp"]["t"])),
+           "transform": mod.transform_x(lib, [f(x) for x in p["transform"]["v"]], [f(x) for x in p["transform"]["column"]], transform_fused),
+           "transform_normal": mod.transform_normal_x(lib, [f(x) for x in p["transform_normal"]["n"]],
+                                                      [f(x) for x in p["transform_normal"]["column"]], transform_normal_fused),
+           "dot": mod.dot(lib, [f(x) for x in p["dot"]["a"]], [f(x) for x in p["dot"]["b"]]),
+           "dot_zero": mod.dot(lib, [f(x) for x in p["dot_zero"]["a"]], [f(x) for x in p["dot_zero"]["b"]])}
+    d = lib.oswr_numerics_fma(); lib.oswr_set_transform_fma(d, d)          # back to the library's default
+    return obs
 
 
 def _select(obs, p):
-    """NumericsProbe.SelectLibrary(): the decision tree of the C# file, restated."""
+    """NumericsProbe.Observe() + SelectLibrary() + Configure(): the decision tree of the C# file, restated.  Nothing here can
+    refuse a combination: each of the three fused-or-not answers is taken on its own."""
     lerp = 1 if obs["lerp"] == p["lerp"]["fused"] else 0 if obs["lerp"] == p["lerp"]["unfused"] else -1
     tr = 1 if obs["transform"] == p["transform"]["fused"] else 0 if obs["transform"] == p["transform"]["unfused"] else -1
-    assert lerp >= 0 and tr >= 0 and lerp == tr
+    tn = 1 if obs["transform_normal"] == p["transform_normal"]["fused"] else 0 if obs["transform_normal"] == p["transform_normal"]["unfused"] else -1
+    assert lerp >= 0 and tr >= 0 and tn >= 0
     if obs["dot"] == p["dot"]["shuffle"]:
         order = 2
     else:
         assert obs["dot"] == p["dot"]["sequential"]
         order = 1 if obs["dot_zero"] == p["dot_zero"]["dpps"] else 0
         assert order == 1 or obs["dot_zero"] == p["dot_zero"]["sequential"]
-    return lerp, order, "libswr_hip" + ("_fma" if lerp else "") + ("_dotpw" if order == 2 else "_dpps" if order == 1 else "") + ".so"
+    return lerp, tr, tn, order, "libswr_hip" + ("_fma" if lerp else "") + ("_dotpw" if order == 2 else "_dpps" if order == 1 else "") + ".so"
 
 
 def test_numerics_probe_table_selects_the_matching_build_for_every_model():
+    """All 2 x 2 x 2 x 3 = 24 System.Numerics models (Transform, TransformNormal, Lerp fused or not; three dot orders) are
+    observed correctly and served: (Lerp, Dot) picks one of six existing libraries, the Transform pair becomes run-time flags."""
     import json
     mod, models = _probe_models()
     table = json.load(open(os.path.join(ROOT, "csharp", "numerics_probe.json")))
     p = table["probes"]
     # the committed operands still separate the models (the expected bits are what the oracle builds compute today)
-    assert p["lerp"]["fused"] != p["lerp"]["unfused"] and p["transform"]["fused"] != p["transform"]["unfused"]
+    for k in ("lerp", "transform", "transform_normal"):
+        assert p[k]["fused"] != p[k]["unfused"], k
     assert p["dot"]["sequential"] != p["dot"]["shuffle"] and p["dot_zero"]["sequential"] != p["dot_zero"]["dpps"]
     libs = {(e["fma"], e["dot"]): e["library"] for e in table["libraries"]}
-    assert set(libs) == set(models)                                        # five builds, five models
+    assert set(libs) == set(models) and len(libs) == 6                     # six builds: every (Lerp, Dot) pair
+    served = 0
     for (fma, dot), olib in models.items():
-        fma_sel, dot_sel, name = _select(_observe(mod, olib, p), p)
-        assert (fma_sel, dot_sel) == (fma, dot) and name == libs[(fma, dot)]
-        path = os.path.join(ROOT, "softwarerenderer_amd", name)
-        assert os.path.exists(path), f"{name} is missing: make -C softwarerenderer_amd/csrc variants"
+        path = os.path.join(ROOT, "softwarerenderer_amd", libs[(fma, dot)])
+        assert os.path.exists(path), f"{libs[(fma, dot)]} is missing: make -C softwarerenderer_amd/csrc variants"
         hip = ctypes.CDLL(path)                                            # loads without a GPU; the query touches no device
         a, b = ctypes.c_int(-1), ctypes.c_int(-1)
         assert hip.swr_numerics_mode(ctypes.byref(a), ctypes.byref(b)) == 0 and (a.value, b.value) == (fma, dot)
+        for tr in (0, 1):
+            for tn in (0, 1):
+                sel = _select(_observe(mod, olib, p, tr, tn), p)
+                assert sel == (fma, tr, tn, dot, libs[(fma, dot)]), (fma, tr, tn, dot, sel)
+                served += 1
+    assert served == 24
+    cs = open(os.path.join(ROOT, "csharp", "RasterizerNative.cs")).read()
+    probe_cs = cs[cs.index("public static class NumericsProbe"):cs.index("public static class SwrContext")]
+    assert "lerpFused != trFused" not in probe_cs and "NumericsProbe.Configure(c);" in cs       # no combination is refused any more
+    assert probe_cs.count("throw new NotSupportedException") == 2                                 # only bit patterns that are neither model's
 
 
 def test_csharp_probe_constants_are_the_generated_ones():
@@ -223,6 +242,8 @@ def test_csharp_probe_constants_are_the_generated_ones():
         (p["lerp"]["a"], p["lerp"]["b"], p["lerp"]["t"], p["lerp"]["unfused"], p["lerp"]["fused"])
     assert arrays["TransformV"] == p["transform"]["v"] and arrays["TransformColumn"] == p["transform"]["column"]
     assert (consts["TransformUnfused"], consts["TransformFused"]) == (p["transform"]["unfused"], p["transform"]["fused"])
+    assert arrays["TransformNormalN"] == p["transform_normal"]["n"] and arrays["TransformNormalColumn"] == p["transform_normal"]["column"]
+    assert (consts["TransformNormalUnfused"], consts["TransformNormalFused"]) == (p["transform_normal"]["unfused"], p["transform_normal"]["fused"])
     assert arrays["DotA"] == p["dot"]["a"] and arrays["DotB"] == p["dot"]["b"]
     assert (consts["DotSequential"], consts["DotShuffle"]) == (p["dot"]["sequential"], p["dot"]["shuffle"])
     assert arrays["DotZeroA"] == p["dot_zero"]["a"] and arrays["DotZeroB"] == p["dot_zero"]["b"]

@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Generates the numerics start-up probe of csharp/RasterizerNative.cs (VERDICT r2 "Next" #3).
 
-Nothing in the reference pins how .NET 9's System.Numerics evaluates Vector4.Transform / Vector4.Lerp (fused multiply-adds or
-not: SWR_NUMERICS_FMA) and Vector3.Dot (order of the lane sum: SWR_DOT_PAIRWISE 0 sequential, 1 dpps, 2 shuffle-adds), and a
-third of cfg3's depth words depend on the first question.  Every model is built on both sides
-(libswr_hip{,_fma,_dotpw,_fma_dotpw,_dpps}.so, oracle/liboswr*.so).  This script searches, with the ORACLE builds as the models,
+Nothing in the reference pins how .NET 9's System.Numerics evaluates Vector4.Transform / Vector3.TransformNormal / Vector4.Lerp
+(fused multiply-adds or not) and Vector3.Dot (order of the lane sum: SWR_DOT_PAIRWISE 0 sequential, 1 dpps, 2 shuffle-adds), and a
+third of cfg3's depth words depend on the first question.  The three fused-or-not questions are INDEPENDENT
+here (round 4): Lerp x dot order is the compile-time axis (six libraries on both sides: libswr_hip{,_fma,_dotpw,_fma_dotpw,_dpps,
+_fma_dpps}.so, oracle/liboswr*.so), Transform and TransformNormal are run-time flags (swr_set_transform_fma /
+oswr_set_transform_fma) -- 2 x 2 x 2 x 3 = 24 models, all served.  This script searches, with the ORACLE builds as the models,
 operands on which the models give different float32 bits:
-    lerp      a, b, t            Vector4.Lerp(a, b, t).X            fused != unfused
-    transform v, column of M     Vector4.Transform(v, M).X          fused != unfused
-    dot       a, b               Vector3.Dot(a, b)                  shuffle-adds != sequential
-    dot_zero  a, b               Vector3.Dot(a, b) (a signed zero)  dpps != sequential (they differ in the sign of a zero only)
+    lerp              a, b, t            Vector4.Lerp(a, b, t).X               fused != unfused
+    transform         v, column of M     Vector4.Transform(v, M).X             fused != unfused
+    transform_normal  n, column of M     Vector3.TransformNormal(n, M).X       fused != unfused
+    dot               a, b               Vector3.Dot(a, b)                     shuffle-adds != sequential
+    dot_zero          a, b               Vector3.Dot(a, b) (a signed zero)     dpps != sequential (they differ in the sign of a zero only)
 and writes them with the expected bit patterns to csharp/numerics_probe.json and into the generated block of
-csharp/RasterizerNative.cs, whose NumericsProbe.SelectLibrary() evaluates the same expressions with the running .NET, compares the
-bits and loads the matching library (or throws on a pattern no build models).  tests/test_abi.py re-derives every expected bit
+csharp/RasterizerNative.cs, whose NumericsProbe evaluates the same expressions with the running .NET, compares the bits, loads the
+matching library and sets the run-time flags (or throws on a bit pattern that is neither model's).  tests/test_abi.py re-derives every expected bit
 pattern from the oracle builds and checks the C# constants against the JSON.   usage: python tools/make_numerics_probe.py"""
 import ctypes as C
 import json
@@ -27,9 +30,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import binding as ob       # noqa: E402   (test infrastructure: this script is a generator, not product code)
 
+# (Lerp fused?, dot order) -> build
 LIBS = {(0, 0): "libswr_hip.so", (1, 0): "libswr_hip_fma.so", (0, 2): "libswr_hip_dotpw.so", (1, 2): "libswr_hip_fma_dotpw.so",
-        (0, 1): "libswr_hip_dpps.so"}
-ORACLES = {(0, 0): "", (1, 0): "fma", (0, 2): "dotpw", (1, 2): "fma_dotpw", (0, 1): "dpps"}
+        (0, 1): "libswr_hip_dpps.so", (1, 1): "libswr_hip_fma_dpps.so"}
+ORACLES = {(0, 0): "", (1, 0): "fma", (0, 2): "dotpw", (1, 2): "fma_dotpw", (0, 1): "dpps", (1, 1): "fma_dpps"}
 
 
 def bits(x):
@@ -43,6 +47,7 @@ def models():
         lib.oswr_nm_lerp.restype = C.c_float; lib.oswr_nm_lerp.argtypes = [C.c_float] * 3
         lib.oswr_nm_dot3.restype = C.c_float; lib.oswr_nm_dot3.argtypes = [C.POINTER(C.c_float)] * 2
         lib.oswr_nm_transform4.restype = None; lib.oswr_nm_transform4.argtypes = [C.POINTER(C.c_float)] * 3
+        lib.oswr_nm_transform_normal3.restype = None; lib.oswr_nm_transform_normal3.argtypes = [C.POINTER(C.c_float)] * 3
         assert (lib.oswr_numerics_fma(), lib.oswr_dot_pairwise()) == key
         out[key] = lib
     return out
@@ -57,12 +62,26 @@ def dot(lib, a, b):
     return bits(lib.oswr_nm_dot3(fa, fb))
 
 
-def transform_x(lib, v, col):
+def transform_x(lib, v, col, fused=None):
+    """Vector4.Transform(v, M).X; fused: the run-time Transform flag to evaluate under (None = leave the library's setting)"""
     m = [0.0] * 16
     for i in range(4):
         m[4 * i] = col[i]                     # M11, M21, M31, M41: the column that makes the result's X
     fv = (C.c_float * 4)(*v); fm = (C.c_float * 16)(*m); fo = (C.c_float * 4)()
+    if fused is not None:
+        lib.oswr_set_transform_fma(int(fused), int(fused))
     lib.oswr_nm_transform4(fv, fm, fo)
+    return bits(fo[0])
+
+
+def transform_normal_x(lib, n, col, fused=None):
+    m = [0.0] * 16
+    for i in range(3):
+        m[4 * i] = col[i]                     # M11, M21, M31
+    fn = (C.c_float * 3)(*n); fm = (C.c_float * 16)(*m); fo = (C.c_float * 3)()
+    if fused is not None:
+        lib.oswr_set_transform_fma(int(fused), int(fused))
+    lib.oswr_nm_transform_normal3(fn, fm, fo)
     return bits(fo[0])
 
 
@@ -78,9 +97,16 @@ def search():
             probe["lerp"] = {"a": bits(a), "b": bits(b), "t": bits(t), "unfused": u, "fused": f}
     while "transform" not in probe:
         v = [float(x) for x in f32(4)]; col = [float(x) for x in f32(4)]
-        u, f = transform_x(M[(0, 0)], v, col), transform_x(M[(1, 0)], v, col)
+        u, f = transform_x(M[(0, 0)], v, col, False), transform_x(M[(0, 0)], v, col, True)
         if u != f:
             probe["transform"] = {"v": [bits(x) for x in v], "column": [bits(x) for x in col], "unfused": u, "fused": f}
+    while "transform_normal" not in probe:
+        n = [float(x) for x in f32(3)]; col = [float(x) for x in f32(3)]
+        u, f = transform_normal_x(M[(0, 0)], n, col, False), transform_normal_x(M[(0, 0)], n, col, True)
+        if u != f:
+            probe["transform_normal"] = {"n": [bits(x) for x in n], "column": [bits(x) for x in col], "unfused": u, "fused": f}
+    for lib in M.values():                                   # leave every library instance at its compile-time default
+        d = lib.oswr_numerics_fma(); lib.oswr_set_transform_fma(d, d)
     while "dot" not in probe:
         a = [float(x) for x in f32(3)]; b = [float(x) for x in f32(3)]
         s, sh = dot(M[(0, 0)], a, b), dot(M[(0, 2)], a, b)
@@ -104,6 +130,8 @@ def csharp_block(p):
         f"        const uint LerpA = {h(p['lerp']['a'])}, LerpB = {h(p['lerp']['b'])}, LerpT = {h(p['lerp']['t'])}, LerpUnfused = {h(p['lerp']['unfused'])}, LerpFused = {h(p['lerp']['fused'])};",
         f"        static readonly uint[] TransformV = {arr(p['transform']['v'])}, TransformColumn = {arr(p['transform']['column'])};",
         f"        const uint TransformUnfused = {h(p['transform']['unfused'])}, TransformFused = {h(p['transform']['fused'])};",
+        f"        static readonly uint[] TransformNormalN = {arr(p['transform_normal']['n'])}, TransformNormalColumn = {arr(p['transform_normal']['column'])};",
+        f"        const uint TransformNormalUnfused = {h(p['transform_normal']['unfused'])}, TransformNormalFused = {h(p['transform_normal']['fused'])};",
         f"        static readonly uint[] DotA = {arr(p['dot']['a'])}, DotB = {arr(p['dot']['b'])};",
         f"        const uint DotSequential = {h(p['dot']['sequential'])}, DotShuffle = {h(p['dot']['shuffle'])};",
         f"        static readonly uint[] DotZeroA = {arr(p['dot_zero']['a'])}, DotZeroB = {arr(p['dot_zero']['b'])};",
@@ -116,7 +144,9 @@ def csharp_block(p):
 def main():
     p = search()
     table = [{"fma": k[0], "dot": k[1], "library": v} for k, v in sorted(LIBS.items())]
-    out = {"generator": "tools/make_numerics_probe.py", "probes": p, "libraries": table}
+    out = {"generator": "tools/make_numerics_probe.py", "probes": p, "libraries": table,
+           "run_time_flags": "swr_set_transform_fma(ctx, transform probe fused?, transform_normal probe fused?) after swr_create; "
+                             "`fma` of a library = the lerp probe"}
     with open(os.path.join(ROOT, "csharp", "numerics_probe.json"), "w") as f:
         json.dump(out, f, indent=1); f.write("\n")
     cs = os.path.join(ROOT, "csharp", "RasterizerNative.cs")
