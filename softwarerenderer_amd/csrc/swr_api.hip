@@ -468,12 +468,12 @@ int bin_and_raster(swr_context* c, RasterSet& S, hipStream_t F, const Batch& b, 
             SWR_HIP(c, hipMemsetAsync(order_hist, 0, 2 * SWR_ORDER_BUCKETS * 4, F));
         }
         hipLaunchKernelGGL(k_bin<false>, dim3(bin_blocks), dim3(256), 0, F, ba);
-        const unsigned scan_blocks = (n_tiles + 1023u) / 1024u;
-        unsigned long long* sums = d_total + 32;      // room for 1024 block sums
-        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(1024), 0, F, (const uint32_t*)ba.tile_count, n_tiles, sums);
+        const unsigned scan_blocks = (n_tiles + (unsigned)SWR_SCAN_BLOCK - 1u) / (unsigned)SWR_SCAN_BLOCK;
+        unsigned long long* sums = d_total + 32;      // room for 4096 block sums (2^20 tiles)
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(SWR_SCAN_BLOCK), 0, F, (const uint32_t*)ba.tile_count, n_tiles, sums);
         // async: the device decides whether the batch fits; sync: the host does (capacity "infinite" here)
         const unsigned long long cap = mode == MODE_ASYNC ? (unsigned long long)ba.list_capacity : ~0ull;
-        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(1024), 0, F, ba.tile_count,
+        hipLaunchKernelGGL(k_scan_apply, dim3(scan_blocks), dim3(SWR_SCAN_BLOCK), 0, F, ba.tile_count,
                            S.d_tile_start.as<uint32_t>(), n_tiles, (const unsigned long long*)sums, d_total,
                            cap, b.seq, c->d_ctrl.as<Ctrl>(), c->d_counters.as<Counters>() + 64,
                            mode == MODE_ASYNC ? 1 : 0, (const uint32_t*)tile_work, order_hist, tile_bucket);
@@ -633,8 +633,8 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     for (size_t i = 0; i < nd; ++i) {
         DrawParams p = b.draws[i].p;
         p.vert_base = (uint32_t)V; p.tri_base = (uint32_t)T;
-        for (uint32_t f = 0; f < p.n_verts; f += 256) vblocks.push_back({ (uint32_t)i, f });
-        for (uint32_t f = 0; f < p.n_tris; f += 256) tblocks.push_back({ (uint32_t)i, f });
+        for (uint32_t f = 0; f < p.n_verts; f += SWR_GEOM_BLOCK) vblocks.push_back({ (uint32_t)i, f });
+        for (uint32_t f = 0; f < p.n_tris; f += SWR_GEOM_BLOCK) tblocks.push_back({ (uint32_t)i, f });
         V += p.n_verts; T += p.n_tris;
         // fragment-stage identity: draws that differ only in geometry / matrices / cull mode share one set of fragment constants
         p.frag_draw = (uint32_t)i;
@@ -654,7 +654,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
         return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
     if (T == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
-    // the per-tile scan (k_scan_sums / k_scan_apply) holds 1024 block sums of 1024 tiles each
+    // the per-tile scan (k_scan_sums / k_scan_apply) holds 4096 block sums of SWR_SCAN_BLOCK = 256 tiles each
     if (n_tiles > (1u << 20))
         return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^20 tiles in one band (a target beyond 16384 x 16384): render it in tile-row bands (swr_set_band)");
 
@@ -720,7 +720,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     fp.near_clip = b.near_clip;
     if (!vblocks.empty()) {
         ScopedSpan sp(c, ST_VERTEX, F);
-        hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(256), 0, F,
+        hipLaunchKernelGGL(k_vertex, dim3((unsigned)vblocks.size()), dim3(SWR_GEOM_BLOCK), 0, F,
                            d_draws, d_vblocks, S.d_vout.as<VOut>(), d_visible,
                            reinterpret_cast<float*>((char*)S.d_upload.p + offsetof(DrawParams, fog_r1)),
                            dbgv ? S.d_vnorm.as<float4>() : (float4*)nullptr, S.d_tile_count.as<uint32_t>(), n_tiles,
@@ -730,7 +730,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const bool counts_clear = !vblocks.empty() && n_tiles != 0;      // k_vertex cleared the per-tile counters and the order histogram
     {
         ScopedSpan sp(c, ST_SETUP, F);
-        hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(256), 0, F,
+        hipLaunchKernelGGL(k_setup, dim3((unsigned)tblocks.size()), dim3(SWR_GEOM_BLOCK), 0, F,
                            d_draws, d_tblocks, (const VOut*)S.d_vout.as<VOut>(),
                            S.d_vout.as<VOut>() + V, (uint32_t)V, S.d_recs.as<TriRec>(),
                            c->d_slot_tb.as<unsigned long long>(), fp, c->d_counters.as<Counters>(),
@@ -899,10 +899,6 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     if (!mesh || !model || !view || !proj) return fail(c, SWR_ERR_INVALID_ARG, "null argument to render_mesh");
     if (program < SWR_PROG_FLAT_COLOR || program > SWR_PROG_DEBUG_VARYINGS)
         return fail(c, SWR_ERR_INVALID_ARG, "unknown program id");
-#if SWR_VARY_GLOBAL == 0
-    if (program == SWR_PROG_DEBUG_VARYINGS)      // (an A/B build of tools/ablate.py: the program lives on the kernels that fetch varyings from HBM)
-        return fail(c, SWR_ERR_UNSUPPORTED, "SWR_PROG_DEBUG_VARYINGS needs a build with SWR_VARY_GLOBAL != 0");
-#endif
     if ((program == SWR_PROG_DUST2_LAMBERT_FOG || program == SWR_PROG_PHONG_4POINT) && !u)
         return fail(c, SWR_ERR_INVALID_ARG, "this program needs a uniform block");
     if (cull < 0 || cull > 2 || depth_test < 0 || depth_test > 7 || blend < 0 || blend > 3)
@@ -1049,13 +1045,15 @@ int swr_create(int device_id, swr_context** out) {
     c->stream = c->own_stream;
     if (ensure_front_stream(c)) { g_create_error = c->err; (void)hipStreamDestroy(c->own_stream); delete c; return SWR_ERR_HIP; }
     { const char* sf = getenv("SWR_SYNC_FLUSH"); c->sync_flush = sf && sf[0] == '1'; }
+#ifdef SWR_TEST_HOOKS       // libswr_hip_test.so only: the FILL pass of optimistic flushes sees a list of n entries (forces the list-overflow path)
     { const char* df = getenv("SWR_DEBUG_FILL_CAPACITY"); c->debug_fill_capacity = df ? (uint32_t)strtoul(df, nullptr, 10) : 0u; }
+#endif
     int rc = ensure(c, c->d_counters, 65 * sizeof(Counters));
     if (!rc) rc = ensure(c, c->d_ctrl, 64);
     if (!rc && hipHostMalloc((void**)&c->host_poison, 64, hipHostMallocDefault) != hipSuccess) rc = SWR_ERR_OOM;
     if (!rc) { memset(c->host_poison, 0, 64); Ctrl fresh; fresh.poison = 0; fresh.first_bad = 0xffffffffu; fresh.need = 0; fresh.host_flag = c->host_poison; if (hipMemcpy(c->d_ctrl.p, &fresh, sizeof fresh, hipMemcpyHostToDevice) != hipSuccess) rc = SWR_ERR_HIP; }
-    if (!rc) rc = ensure(c, c->d_total, 256 + 1024 * 8);
-    if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 1024 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
+    if (!rc) rc = ensure(c, c->d_total, 256 + 4096 * 8);
+    if (!rc && hipMemsetAsync(c->d_total.p, 0, 256 + 4096 * 8, c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (!rc && hipMemsetAsync(c->d_counters.p, 0, 65 * sizeof(Counters), c->stream) != hipSuccess) rc = SWR_ERR_HIP;
     if (rc) { g_create_error = c->err; swr_destroy(c); return rc; }
     *out = c;

@@ -385,7 +385,7 @@ __device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot,
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_bin(BinArgs a) {
+__global__ __launch_bounds__(256, 8) void k_bin(BinArgs a) {       // (8 waves per SIMD = 64 VGPRs: beside the raster kernel, swr_device.h)
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && batch_poisoned(a.ctrl, a.seq)) return;
@@ -415,9 +415,11 @@ __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
 // Exclusive scan of the per-tile counts in two launches (no inter-block waiting, no dispatch-order assumption; a single launch that
 // hands out tickets and exchanges the chunk sums through memory was built and measured: 0.0669 against 0.0667 ms for the bin stage --
 // the exchange's dependent round trips cost what the second launch costs -- and it spins, so it was not kept):
-//   k_scan_sums : block b sums its 1024 counts -> sums[b]
-//   k_scan_apply: block b adds sums[0..b) (<= 256 values at 8192^2) to a local scan of its 1024 counts
-__device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long v, unsigned long long* s_part) {
+//   k_scan_sums : block b sums its SWR_SCAN_BLOCK counts -> sums[b]
+//   k_scan_apply: block b adds sums[0..b) (<= 1024 values at 8192^2, 4096 at the 2^20-tile limit) to a local scan of its counts
+// Blocks of 256 threads (round 3: 1024): a 16-wave workgroup never fits beside a raster kernel (swr_device.h, SWR_FRONT_MAX_LDS).
+#define SWR_SCAN_BLOCK 256
+__device__ __forceinline__ unsigned long long block_sum(unsigned long long v, unsigned long long* s_part) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
@@ -426,33 +428,36 @@ __device__ __forceinline__ unsigned long long block_sum_1024(unsigned long long 
     if ((threadIdx.x & 63u) == 0u) s_part[threadIdx.x >> 6] = v;
     __syncthreads();
     unsigned long long t = 0;
-    for (int w = 0; w < 16; ++w) t += s_part[w];
+    for (int w = 0; w < SWR_SCAN_BLOCK / 64; ++w) t += s_part[w];
     return t;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
+__global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
                                                     unsigned long long* __restrict__ sums) {
-    __shared__ unsigned long long s_part[16];
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
-    const unsigned long long t = block_sum_1024(i < n ? count[i] : 0u, s_part);
+    __shared__ unsigned long long s_part[SWR_SCAN_BLOCK / 64];
+    const uint32_t i = blockIdx.x * (uint32_t)SWR_SCAN_BLOCK + threadIdx.x;
+    const unsigned long long t = block_sum(i < n ? count[i] : 0u, s_part);
     if (threadIdx.x == 0) sums[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ count, uint32_t* __restrict__ start,
+__global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_apply(uint32_t* __restrict__ count, uint32_t* __restrict__ start,
                                                      uint32_t n, const unsigned long long* __restrict__ sums,
                                                      unsigned long long* __restrict__ total_out,
                                                      unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
                                                      Counters* __restrict__ counters, int poison_on_overflow,
                                                      const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order_hist,
                                                      uint8_t* __restrict__ tile_bucket) {
-    __shared__ unsigned long long s_part[16];
-    __shared__ unsigned long long s_wave[16];
+    __shared__ unsigned long long s_part[SWR_SCAN_BLOCK / 64];
+    __shared__ unsigned long long s_wave[SWR_SCAN_BLOCK / 64];
     __shared__ uint32_t s_oh[SWR_ORDER_BUCKETS];
+    static_assert(SWR_ORDER_BUCKETS <= SWR_SCAN_BLOCK, "one thread per bucket clears / flushes the block's histogram");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    if (tid < (uint32_t)SWR_ORDER_BUCKETS) s_oh[tid] = 0u;          // (block_sum_1024 below has the barrier)
-    // offset of this block = sum of the earlier blocks' sums (gridDim.x <= 1024)
-    const unsigned long long off = block_sum_1024(tid < blockIdx.x ? sums[tid] : 0ull, s_part);
-    const uint32_t i = blockIdx.x * 1024u + tid;
+    if (tid < (uint32_t)SWR_ORDER_BUCKETS) s_oh[tid] = 0u;          // (block_sum below has the barrier)
+    // offset of this block = sum of the earlier blocks' sums (gridDim.x <= 4096)
+    unsigned long long mine = 0ull;
+    for (uint32_t j = tid; j < blockIdx.x; j += (uint32_t)SWR_SCAN_BLOCK) mine += sums[j];
+    const unsigned long long off = block_sum(mine, s_part);
+    const uint32_t i = blockIdx.x * (uint32_t)SWR_SCAN_BLOCK + tid;
     const uint32_t c = i < n ? count[i] : 0u;
     // the tile's place in the raster kernel's dispatch order: bucket of its weight (see order_bucket), histogram of the buckets
     if (i < n) {
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(1024) void k_scan_apply(uint32_t* __restrict__ coun
         start[i] = (uint32_t)min(excl, 0xffffffffull);
         count[i] = 0u;              // k_bin<FILL> uses the counts as cursors and rebuilds them: no separate clear
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 1023u) {
+    if (blockIdx.x == gridDim.x - 1 && tid == (uint32_t)SWR_SCAN_BLOCK - 1u) {
         const unsigned long long total = excl + c;
         *total_out = total;
         if (total > capacity) {                     // does not fit: poison this and every later batch
@@ -515,7 +520,7 @@ __device__ __forceinline__ void cmpx_glb(uint32_t* g, uint32_t i, uint32_t p, ui
 // barrier).  A tile's sort is ~850 cycles of one wave, and 65,536 waves that short are bound by the rate at which waves can be
 // launched (about one per clock chip-wide: 3.5 waves resident per CU on average, 26 us); fewer, longer waves are not.
 #ifndef SWR_SORT_TPB
-#define SWR_SORT_TPB 4
+#define SWR_SORT_TPB 1                 // (round 3: 4 -- 32 KB of LDS per block; one wave and 8 KB fit beside the raster kernel, swr_device.h)
 #endif
 #ifndef SWR_SORT_TPW
 #define SWR_SORT_TPW 4
@@ -599,13 +604,14 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
     }
 }
 
-__global__ __launch_bounds__(64 * SWR_SORT_TPB) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(64 * SWR_SORT_TPB) SWR_FRONT_VGPRS void k_sort_tiles(const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_list, uint32_t n_tiles,
                                                    uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl, uint32_t seq,
                                                    const uint32_t* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
                                                        pairs sort for 10+ us in one wave and must not start last */) {
     __shared__ uint32_t s_keys_all[SWR_SORT_TPB][SWR_SORT_LDS];
+    static_assert(sizeof(s_keys_all) <= SWR_FRONT_MAX_LDS, "k_sort_tiles must fit beside the raster kernel (swr_device.h)");
     if (batch_poisoned(ctrl, seq)) return;
     static_assert(SWR_SORT_TPW <= 64, "one lane per tile of the wave fetches its count and start");
     const uint32_t first = (blockIdx.x * SWR_SORT_TPB + (threadIdx.x >> 6)) * SWR_SORT_TPW;

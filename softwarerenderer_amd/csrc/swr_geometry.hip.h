@@ -15,11 +15,11 @@
 
 namespace swr {
 
-// one 256-thread block handles up to 256 consecutive vertices / triangles of ONE draw,
+// one SWR_GEOM_BLOCK-thread block handles up to that many consecutive vertices / triangles of ONE draw,
 // so the draw's matrices are wave-uniform (scalar loads)
 struct BlockMap { uint32_t draw; uint32_t first; };
 
-__global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ draws,
+__global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const DrawParams* __restrict__ draws,
                                                 const BlockMap* __restrict__ blocks,
                                                 VOut* __restrict__ vout, const uint32_t* __restrict__ visible,
                                                 float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */,
@@ -28,9 +28,9 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
                                                 uint32_t* __restrict__ zero_words, uint32_t n_zero /* binning's per-tile counters: cleared
                                                                               here, not by a launch of their own */,
                                                 uint32_t* __restrict__ zero_hist /* and the tile order's histogram + cursors */) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero_words[i] = 0u;
-    if (blockIdx.x == 0) { zero_hist[threadIdx.x] = 0u; zero_hist[256 + threadIdx.x] = 0u; }
-    // (2 x SWR_ORDER_BUCKETS words, swr_binning.hip.h)
+    for (uint32_t i = blockIdx.x * (uint32_t)SWR_GEOM_BLOCK + threadIdx.x; i < n_zero; i += gridDim.x * (uint32_t)SWR_GEOM_BLOCK) zero_words[i] = 0u;
+    if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < 512u; i += (uint32_t)SWR_GEOM_BLOCK) zero_hist[i] = 0u;
+    // (2 x SWR_ORDER_BUCKETS = 512 words, swr_binning.hip.h)
     const BlockMap bm = blocks[blockIdx.x];
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
@@ -39,7 +39,8 @@ __global__ __launch_bounds__(256) void k_vertex(const DrawParams* __restrict__ d
     // A lane's 64-byte record leaves as four 16-byte stores, 64 bytes apart from its neighbour's: 256 partial line writes per wave.
     // The wave's 64 records go through LDS instead and leave as four stores of 1 KB each (consecutive lanes, consecutive 16 bytes).
     // (and the other way round for the 48-byte input vertices: three loads of 1 KB each per wave, handed out through LDS)
-    __shared__ float4 s_out[4][256];
+    __shared__ float4 s_out[SWR_GEOM_BLOCK / 64][256];
+    static_assert(sizeof(s_out) <= SWR_FRONT_MAX_LDS, "k_vertex must fit beside the raster kernel (swr_device.h)");
     float4 o0 = make_float4(0.f, 0.f, 0.f, 0.f), o1 = o0, o2 = o0, o3 = o0;
     const bool live = local < dp->n_verts;
     const uint32_t wv_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63u;
@@ -253,10 +254,8 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 #else
 #define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
 #endif
-#ifndef SWR_SETUP_MINBLOCKS
-#define SWR_SETUP_MINBLOCKS 1
-#endif
-__global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawParams* __restrict__ draws,
+__global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves per SIMD = 64 VGPRs: beside the raster kernel, swr_device.h)
+        const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
                                                VOut* __restrict__ clip_pool,     // 4 VOut per triangle, indexed by global triangle
@@ -376,7 +375,8 @@ __global__ __launch_bounds__(256, SWR_SETUP_MINBLOCKS) void k_setup(const DrawPa
     // A lane's 64-byte TriRec would leave as four 16-byte stores, 128 bytes apart from its neighbour's (256 partial line writes per
     // wave: 16 of the kernel's 37 us).  The wave's records go through LDS and leave as four stores of sixteen whole records each.
     {
-        __shared__ float4 s_rec[4][256];
+        __shared__ float4 s_rec[SWR_GEOM_BLOCK / 64][256];
+        static_assert(sizeof(s_rec) + 16 <= SWR_FRONT_MAX_LDS, "k_setup must fit beside the raster kernel (swr_device.h)");
         const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         const unsigned long long vmask = __ballot(rec_valid);
         if (vmask) {                                                   // wave-uniform

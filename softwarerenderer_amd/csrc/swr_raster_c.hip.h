@@ -73,18 +73,6 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 // minimum over the wave (same DPP ladder; the last lane ends up with the result).  v_min_f32 with a DPP source operand:
 // a lane whose source lane does not exist is not written (no bound_ctrl), i.e. keeps its value; s_nop 1 = the two wait
 // states a DPP read needs after a VALU write of the same register.  NaNs are dropped like fminf does.
-#ifdef SWR_NO_ASM_MIN
-__device__ __forceinline__ float wave_min(float x) {
-    const int big = __float_as_int(3.0e38f);
-    int v = __float_as_int(x);
-#define SWR_MIN_STEP(ctrl, rows) { const int t = __builtin_amdgcn_update_dpp(big, v, ctrl, rows, 0xf, false); \
-                                   v = __float_as_int(fminf(__int_as_float(v), __int_as_float(t))); }
-    SWR_MIN_STEP(0x111, 0xf) SWR_MIN_STEP(0x112, 0xf) SWR_MIN_STEP(0x114, 0xf) SWR_MIN_STEP(0x118, 0xf)
-    SWR_MIN_STEP(0x142, 0xa) SWR_MIN_STEP(0x143, 0xc)
-#undef SWR_MIN_STEP
-    return __int_as_float(__builtin_amdgcn_readlane(v, 63));
-}
-#else
 __device__ __forceinline__ float wave_min(float x) {
     asm("s_nop 1\n"
                  "v_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
@@ -96,7 +84,6 @@ __device__ __forceinline__ float wave_min(float x) {
                  : "+v"(x));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
-#endif
 
 struct CoverArgs {
     const TriRec* __restrict__ recs;
@@ -115,49 +102,34 @@ struct CoverArgs {
 };
 
 // pairs (= threads) per k_cover block, and the quantisation of the shape sort's key (rows, columns)
-#ifndef SWR_COVER_BLOCK
 #define SWR_COVER_BLOCK 256
-#endif
-#ifndef SWR_COVER_HQ
 #define SWR_COVER_HQ 1                  // rows exact, columns in fours: 92 instead of 101 executed pixel steps per lane (49 useful), cover -2 %
-#endif
-#ifndef SWR_COVER_WQ
 #define SWR_COVER_WQ 4
-#endif
 // LINES: the batch is DebugMode.Wireframe (DrawLine records); compiled out of the filled-triangle instantiation
 template <bool LINES>
-__global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
+__global__ __launch_bounds__(SWR_COVER_BLOCK) SWR_FRONT_VGPRS void k_cover(CoverArgs a) {
     constexpr int CB = SWR_COVER_BLOCK;
-#ifdef SWR_COVER_SORT_AREA
-    constexpr int NB = 33;
-#else
     constexpr int NB = 1 + (16 / SWR_COVER_HQ) * (16 / SWR_COVER_WQ);
-#endif
-    __shared__ uint16_t s_rows[CB][18];       // 16 row masks per lane (+2 pad: 9 dwords per lane, conflict-free)
+    // One LDS record of 18 halfwords per pair (9 dwords per lane: conflict-free), used three ways in turn by exactly two lanes -- the
+    // pair's own thread and the lane that walks it -- so nothing else is needed (round 3 kept the list entries and the bound in arrays
+    // of their own: 13,088 B; this is 10,004 B, and a block that fits in 10,240 B runs BESIDE the previous flush's raster kernel,
+    // swr_device.h):  [0..3] the pair's list entries {slot, tile} as the own thread read them, in pair order (handed to the walker
+    // before the sort's barriers);  then [0..15] the 16 row masks the walker produces;  [16..17] its hi-Z bound (float bits).
+    // Results leave in PAIR order, not in the walk's sorted order: after a barrier thread t packs and stores pair t -- consecutive
+    // lanes, consecutive addresses (in sorted order every lane's 16-byte stores went to a different line: k_cover is memory bound,
+    // and scattered partial-line writes are what cost k_setup 16 of its 37 us).  All accesses are halfword accesses on purpose: one
+    // type, so the compiler keeps the walker's reads of [0..3] ahead of its own clearing stores.
+    __shared__ uint16_t s_rows[CB][18];
     __shared__ uint32_t s_hist[NB];           // work sort: pairs per bucket, then bucket bases
     __shared__ uint16_t s_perm[CB];           // sorted position -> thread whose pair it is
-#ifndef SWR_COVER_NO_EXCHANGE
-    __shared__ uint32_t s_slot[CB], s_tile[CB];   // the pair's list entries, read once in pair order and handed to the lane that walks it
-#endif
-    // Results leave in PAIR order, not in the walk's sorted order: the walking lane leaves its rows in the LDS row of the pair's own
-    // thread and its hi-Z bound in s_zb, and after a barrier thread t packs and stores pair t -- consecutive lanes, consecutive
-    // addresses (in sorted order every lane's 16-byte stores went to a different line: k_cover is memory bound, and scattered
-    // partial-line writes are what cost k_setup 16 of its 37 us).  SWR_COVER_SORTED_OUT: round 2's stores (A/B).
-#ifndef SWR_COVER_SORTED_OUT
-    __shared__ float s_zb[CB];
-#endif
     __shared__ uint32_t s_wmax[CB / 64];      // per wave: widest bbox /\ tile among its lanes on the fast path
-#ifdef SWR_DEBUG_COVER
-    __shared__ uint32_t s_hmax[CB / 64];
-    if (threadIdx.x < CB / 64) s_hmax[threadIdx.x] = 0u;
-#endif
+    static_assert(sizeof(s_rows) + sizeof(s_hist) + sizeof(s_perm) + sizeof(s_wmax) + 64 <= SWR_FRONT_MAX_LDS, "k_cover must fit beside the raster kernel");
     if (batch_poisoned(a.ctrl, a.seq)) return;
     const uint32_t n_pairs = (uint32_t)*a.n_pairs;
     // Workgroups go round-robin to the 8 XCDs, each with an L2 of its own, and a triangle's pairs sit in neighbouring tiles: the one to
     // the right a few dozen pairs away, the one below a whole tile row (thousands of pairs) away.  XCD x therefore takes the x-th
     // CONTIGUOUS eighth of the pair array (of the pairs that exist, not of the grid, which covers the list capacity): the block that
     // meets a TriRec again a tile row later runs on the same XCD while the line is still in its L2.  SWR_COVER_LINEAR_BLOCKS: A/B.
-#ifndef SWR_COVER_LINEAR_BLOCKS
     uint32_t block;
     {
         const uint32_t nb = (n_pairs + (uint32_t)CB - 1u) / (uint32_t)CB, per_xcd = (nb + 7u) >> 3;
@@ -165,9 +137,6 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         if (k >= per_xcd) return;                                   // (block-uniform)
         block = xcd * per_xcd + k;
     }
-#else
-    const uint32_t block = blockIdx.x;
-#endif
     const uint32_t p_own = block * (uint32_t)CB + threadIdx.x;
     // A lane's loop length is the area of bbox /\ tile (1..256 pixels) and a wave runs as long as its longest lane, so
     // the block first sorts its 256 pairs by that area (counting sort in LDS): each wave then holds pairs of similar
@@ -180,32 +149,24 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         int area = 0;
         if (p_own < n_pairs) {
             const uint32_t slot = a.tile_list[p_own], tile = a.pair_tile[p_own];
-#ifndef SWR_COVER_NO_EXCHANGE
-            s_slot[threadIdx.x] = slot; s_tile[threadIdx.x] = tile;
-#endif
+            s_rows[threadIdx.x][0] = (uint16_t)slot; s_rows[threadIdx.x][1] = (uint16_t)(slot >> 16);
+            s_rows[threadIdx.x][2] = (uint16_t)tile; s_rows[threadIdx.x][3] = (uint16_t)(tile >> 16);
             const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
             const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
             const float4 r3 = reinterpret_cast<const float4*>(a.recs + slot)[3];
-#ifndef SWR_COVER_SORTED_OUT
             {   // {slot, vertex references of outputs[0..2]}: words 10, 11, 12 of the TriRec
                 const float2 r2zw = reinterpret_cast<const float2*>(a.recs + slot)[5];
                 a.refs[p_own] = make_uint4(slot, __float_as_uint(r2zw.x), __float_as_uint(r2zw.y), __float_as_uint(r3.x));
             }
-#endif
             const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
             const int w = min((int)(bbx >> 16), min(x0 + SWR_TILE - 1, a.fp.width - 1)) - max((int)(bbx & 0xffffu), x0) + 1;
             const int h = min((int)(bby >> 16), min(y0 + SWR_TILE - 1, a.fp.height - 1)) - max((int)(bby & 0xffffu), y0) + 1;
             area = (w > 0 && h > 0) ? w * h : 0;
-#ifndef SWR_COVER_SORT_AREA
             // a wave walks max-height rows x max-width columns of its lanes, so group by SHAPE, not just area: bucket = (rows, columns)
             // quantised to SWR_COVER_HQ / SWR_COVER_WQ -- 1 + 16 * 4 buckets, tallest / widest first (0 = nothing to walk)
             if (area > 0) area = 1 + ((h + SWR_COVER_HQ - 1) / SWR_COVER_HQ - 1) * (16 / SWR_COVER_WQ) + ((w + SWR_COVER_WQ - 1) / SWR_COVER_WQ - 1);
         }
         bucket = (uint32_t)area;                                 // 0..NB-1
-#else
-        }
-        bucket = (uint32_t)(area + 7) >> 3;                      // 0..32
-#endif
         rank = atomicAdd(&s_hist[bucket], 1u);
     }
     __syncthreads();
@@ -218,11 +179,9 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     __syncthreads();
     const uint32_t owner = s_perm[threadIdx.x];
     const uint32_t p = block * (uint32_t)CB + owner;
-#ifndef SWR_COVER_SORTED_OUT
     uint16_t* mrow16 = s_rows[owner];
-#else
-    uint16_t* mrow16 = s_rows[threadIdx.x];
-#endif
+    // (the pair's list entries, left there by its own thread before the sort's barriers; read before the rows are cleared)
+    const uint32_t slot_w = (uint32_t)mrow16[0] | ((uint32_t)mrow16[1] << 16), tile_w = (uint32_t)mrow16[2] | ((uint32_t)mrow16[3] << 16);
 #pragma unroll
     for (int i = 0; i < 16; ++i) mrow16[i] = 0;
     // pack 16 row masks into the pair's 256-bit mask, count them, flag rows that are not one run; store mask and info of pair `pi`
@@ -251,20 +210,12 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         a.info[pi] = make_uint2((uint32_t)cnt | (not_run == 0u ? SWR_INFO_SIMPLE : 0u), __float_as_uint(zb));
     };
     if (p < n_pairs) {
-#ifndef SWR_COVER_NO_EXCHANGE
-        const uint32_t slot = s_slot[owner], tile = s_tile[owner];      // (written before the sort's barriers)
-#else
-        const uint32_t slot = a.tile_list[p];
-        const uint32_t tile = a.pair_tile[p];
-#endif
+        const uint32_t slot = slot_w, tile = tile_w;
         const int tx = (int)(tile % (uint32_t)a.fp.tiles_x), ty = band_global_row(band_map(a.fp), (int)(tile / (uint32_t)a.fp.tiles_x));
         const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
         const int tile_end_x = min(x0 + SWR_TILE - 1, a.fp.width - 1), tile_end_y = min(y0 + SWR_TILE - 1, a.fp.height - 1);
         const float4* __restrict__ rq = reinterpret_cast<const float4*>(a.recs + slot);
         const float4 r0 = rq[0], r1 = rq[1], r2 = rq[2], r3 = rq[3];      // (r3 through LDS as well: no change, measured)
-#ifdef SWR_COVER_SORTED_OUT
-        a.refs[p] = make_uint4(slot, __float_as_uint(r2.z), __float_as_uint(r2.w), __float_as_uint(r3.x));
-#endif
         const float s0x = r0.x, s1x = r0.y, s2x = r0.z, s0y = r0.w, s1y = r1.x, s2y = r1.y;
         const uint32_t bbx = __float_as_uint(r3.y), bby = __float_as_uint(r3.z);
         const int startX = max((int)(bbx & 0xffffu), x0), endX = min((int)(bbx >> 16), tile_end_x);     // Rasterizer.cs:471-474
@@ -277,11 +228,7 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
         // 39.3uS of the exact affine depth; that is maximal at a corner of R; the corners evaluated in float below are
         // within 7.3uS; margin used: 64uS.  Lines and non-finite cases get +inf (never hidden).
         float zbound = __uint_as_float(0x7f800000u);
-#ifndef SWR_ABL_NOZBOUND
         if (!is_line && startX <= endX && startY <= endY) {
-#else
-        if (false) {
-#endif
             const float fxs = (float)startX, fxe = (float)endX, fys = (float)startY, fye = (float)endY;
             const float sx[3] = { r0.x, r0.y, r0.z }, sy[3] = { r0.w, r1.x, r1.y };
             const float dd[3] = { r1.z, r1.w, r2.x };
@@ -334,20 +281,12 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
                 // shift-or -- no per-lane loop bookkeeping.  A narrower lane steps past its endX; those values are
                 // never looked at (colmask) and stay finite (<= 31 adds of values below 1e30).
                 const int width = endX - startX + 1;
-#ifdef SWR_DEBUG_COVER
-                atomicMax(&s_hmax[threadIdx.x >> 6], (uint32_t)(endY - startY + 1));
-                atomicAdd(&a.dbg[0], (unsigned long long)(width * (endY - startY + 1)));
-#endif
                 atomicMax(&s_wmax[threadIdx.x >> 6], (uint32_t)width);
                 SWR_WAVE_LDS_FENCE_REAL();        // cold (once per lane and 256-pair block): the real fence costs nothing measurable here
                 const int wsteps = __builtin_amdgcn_readfirstlane((int)s_wmax[threadIdx.x >> 6]);
                 const uint32_t colmask = (1u << width) - 1u;
                 const int sh = startX - x0;
-#ifdef SWR_ABL_NOCOVERLOOP      // tools/ablate.py timing experiments only (wrong image by design)
-                for (int y = startY; y <= startY; ++y) {
-#else
                 for (int y = startY; y <= endY; ++y) {
-#endif
                     float w0 = w0r, w1 = w1r, w2 = w2r;
                     uint32_t acc = 0;                      // pixel startX + i ends at bit wsteps - 1 - i
                     for (int i = 0; i < wsteps; ++i) {
@@ -386,23 +325,13 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
                 }
             }
         }
-#ifdef SWR_COVER_SORTED_OUT
-        emit(mrow16, p, zbound);
-#else
-        s_zb[owner] = zbound;
-#endif
+        mrow16[16] = (uint16_t)__float_as_uint(zbound); mrow16[17] = (uint16_t)(__float_as_uint(zbound) >> 16);
     }
-#ifndef SWR_COVER_SORTED_OUT
     __syncthreads();
-    if (p_own < n_pairs) emit(s_rows[threadIdx.x], p_own, s_zb[threadIdx.x]);
-#endif
-#ifdef SWR_DEBUG_COVER
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.dbg[1], (unsigned long long)(64u * s_wmax[threadIdx.x >> 6] * s_hmax[threadIdx.x >> 6]));
-        atomicAdd(&a.dbg[2], 1ull);
+    if (p_own < n_pairs) {
+        const uint16_t* own = s_rows[threadIdx.x];
+        emit(own, p_own, __uint_as_float((uint32_t)own[16] | ((uint32_t)own[17] << 16)));
     }
-#endif
     // (round 2 summed the counts per tile here -- the raster kernel's scheduling weight -- with a block barrier, a wave scan and an
     //  atomic per run of equal tiles; the weight now comes from the raster kernel's own count of the previous flush, swr_binning.hip.h)
 }
@@ -410,89 +339,51 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
 // pairs per batch.  Everything a fragment needs from its triangle (the TriRec and the three outputs' varyings)
 // is staged in LDS once per batch by one lane per pair: per-fragment gathers of that data (256 B per fragment
 // through the vector L1, which is what bounded the kernel) become LDS broadcasts.
-#ifndef SWR_BATCH
 #define SWR_BATCH 16
-#endif
-#ifndef SWR_BATCH_FRAGS
 #define SWR_BATCH_FRAGS 2048                   // fragments per batch (a pair covers <= 256 pixels, so at least 8 pairs always fit)
-#endif
-#ifndef SWR_WINDOW
 #define SWR_WINDOW 32                          // candidate pairs examined per batch (<= 64)
-#endif
-// The kernels that carry the 4-light program's extra varyings (PHONG: 16 instead of 13 staged rows per pair) would need 10,960 B
-// with 16 pairs: 14 waves per CU instead of 16.  They stage 12 pairs (9,600 B): cfg4's raster kernel -8 % (13 pairs: -6 %).
-#ifndef SWR_BATCH_PHONG
-#define SWR_BATCH_PHONG 12
-#endif
-#ifndef SWR_WINDOW_PHONG
-#define SWR_WINDOW_PHONG 24
-#endif
-// Where the three outputs' varyings of a pair come from when a fragment is shaded (SWR_VARY_GLOBAL; VG in the code):
+// (every size here was swept: 8 / 12 / 13 / 20 / 24 / 28-pair batches, windows of 24-64, 1536 fragments -- profiles/r02_final_ablations.txt,
+//  profiles/r03_raster_experiments.md; the switches are gone, the numbers stay)
+// Where the three outputs' varyings of a pair come from when a fragment is shaded (VG in the code):
 //   staged in LDS (round 2's layout): nine rows per pair (twelve with the 4-light program's world position), 292 B per pair;
 //   from the vertex-stage output in HBM: buffer loads with staged byte offsets -- the lanes of one pair read the same 16-byte rows,
 //     a chunk touches the vertices of 3-4 pairs -- and only what the chain replay, the depth test and Interpolate's divisions need
 //     stays staged: 176 B per pair, 8,336 B per wave with 16 pairs = 18 waves per CU instead of 16 (LDS is allocated in units of
 //     1,280 B, tools/ubench/lds_occupancy.hip).
 // Measured on cfg3 (profiles/r03_raster_experiments.md): the loads cost 7 % at equal occupancy and the two extra waves return 4-5 %,
-// so the kernels WITHOUT the 4-light program keep the staged layout; the kernels that carry it (PHONG = true: they had to shrink
-// their batch to 12 pairs to stay at 16 waves) take the loads: 16 pairs per batch again and 18 waves, cfg4 -5 %.
-//   0 = always staged, 1 = always from HBM, 2 (default) = from HBM in the PHONG kernels only
-#ifndef SWR_VARY_GLOBAL
-#define SWR_VARY_GLOBAL 2
-#endif
-#ifndef SWR_RASTER_MINWAVES
-#define SWR_RASTER_MINWAVES 4
-#endif
-// when the rows are requested (VG): 0 = by the fragments that passed the depth test, 1 = by every fragment of the chunk as soon as
-// its pair is known (ahead of the election), 2 = by the fragments that survive the chunk's cut (ahead of the chain replay; spills),
-// 3 = as 2 but only the uv rows, the texel address hangs on them (cfg3: 0.4333 / 0.4303 / 0.4241 / 0.4290 ms for 0 / 1 / 2 / 3)
-#ifndef SWR_VARY_EARLY
-#define SWR_VARY_EARLY 3
-#endif
-// the DUST2 kernel shades with the straight-line speculate-then-verify shader (shade_dust2_fast, swr_raster.hip.h); 0 = always shade_fragment
-#ifndef SWR_FAST_SHADE
-#define SWR_FAST_SHADE 1
-#endif
+// so the kernels WITHOUT the 4-light program keep the staged layout (VG = false); the kernels that carry it (PHONG = true: staged, they
+// had to shrink their batch to 12 pairs to stay at 16 waves) take the loads (VG = true): 16 pairs per batch again and 18 waves, cfg4 -5 %.
+// When the rows are requested (VG): the uv rows by the fragments that survive the chunk's cut, ahead of the chain replay (the texel
+// address hangs on them), the rest by the fragments that passed the depth test (cfg3, all kernels VG: 0.4290 ms against 0.4333 for
+// everything after the depth test, 0.4303 for everything ahead of the election, 0.4241 but spilling for everything after the cut).
+// The DUST2 kernel shades with the straight-line speculate-then-verify shader (shade_dust2_fast, swr_raster.hip.h).
 // staged float4 rows per pair (everything per-pair is computed once here instead of once per fragment):
 //   0: edge values at the pair's first pixel (w0,w1,w2 of Rasterizer.cs:481-483), invArea   [lines: t0x,t1x,t0y,t1y]
 //   1: depths[0..2], draw/flags word          2: column steps a12,a20,a01, first pixel (x,y inside the tile, 8 bits each)
 //   3: row steps b12,b20,b01, stream position of the pair's first fragment (int bits)
-//   SWR_VARY_GLOBAL: 4: byte offsets of outputs[0..2] in the VOut array, clip.w of outputs[0]
+//   VG:              4: byte offsets of outputs[0..2] in the VOut array, clip.w of outputs[0]
 //                    5: refined reciprocals of the three clip.w (Interpolate's divisions, see div_core), clip.w of outputs[1]
 //                    (clip.w of outputs[2] rides in the row-start entry)
 //                    6: byte offset of the pair's TriRec (DEBUG_VARYINGS reads the three screen positions from it)
 //   else 4-6 / 7-9 / 10-12: outputs[0] / [1] / [2] as {clip (x replaced by the output's wn.z, y by the refined reciprocal of clip.w),
 //   color, uv + wn.xy};  PHONG adds 13-15 = {wn.z, wpos} of each
-#ifdef SWR_ABL_VARY_ALIAS
-#define SWR_VROW(r, idx) L.stagev[((r) >= 4 ? (r) - 4 : 0)][(idx) % WaveLdsC<PHONG>::VB]
-#else
 #define SWR_VROW(r, idx) L.stage[r][idx]
-#endif
 template <bool PHONG>
 struct __attribute__((aligned(16))) WaveLdsC {
-    static constexpr bool VG = SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG);
-    static constexpr int NQ = VG ? 7 : (PHONG ? 16 : 13);
-    static constexpr int BATCH = (PHONG && !VG) ? SWR_BATCH_PHONG : SWR_BATCH;       // pairs staged per batch
-    static constexpr int WINDOW = (PHONG && !VG) ? SWR_WINDOW_PHONG : SWR_WINDOW;    // candidate pairs examined per batch
+    static constexpr bool VG = PHONG;
+    static constexpr int NQ = VG ? 7 : 13;
+    static constexpr int BATCH = SWR_BATCH;        // pairs staged per batch
+    static constexpr int WINDOW = SWR_WINDOW;      // candidate pairs examined per batch
     static constexpr int RT_ROWS = VG ? 8 : 4;     // a row-start entry every RT_ROWS rows of a pair
     static constexpr int RT_N = 16 / RT_ROWS - 1;  // entries per pair (rows RT_ROWS, 2 RT_ROWS, ...)
     float4 col[256];                 // pixel p = (y - y0) * 16 + (x - x0)
     float z[256];
-#ifdef SWR_ABL_VARY_ALIAS            // tools/ablate.py occupancy probe: the varying rows of only this many pairs exist (pair t uses t % n: wrong
-    static constexpr int VB = SWR_ABL_VARY_ALIAS;     // colours, identical work): the layout shrinks without changing the instruction stream
-    float4 stage[4][BATCH];
-    float4 stagev[NQ - 4][VB];
-#else
     float4 stage[NQ][BATCH];         // batch (non-empty pairs only, compacted): per-pair fragment inputs
-#endif
     uint32_t mask[BATCH][8];         // coverage masks
     uint32_t wpre[BATCH][4];         // exclusive prefix of the 8 word popcounts, 16-bit fields (word j -> field j)
     uint32_t head[SWR_BATCH_FRAGS / 32 + 4];   // bit (first - 1) set for every pair t >= 1 (first = its stream position): pair of fragment g = #bits below g
     uint32_t touched[32];            // chunk duplicate election: pixel p claimed <=> bit (p >> 5) of word (p & 31) -- neighbouring
                                      // pixels (the usual content of a chunk) fall into different words: no same-address atomics
-#ifdef SWR_ABL_LDSBYTES             // tools/ablate.py occupancy probe: dead LDS that lowers the waves per SIMD, nothing else changes
-    uint32_t abl_pad[SWR_ABL_LDSBYTES / 4];
-#endif
     // row-start table: the pair's edge values at the start of its rows RT_ROWS (q + 1), q = 0 .. RT_N - 1, i.e. the reference's row chain
     // (Rasterizer.cs:532-534) run once per pair at staging: a fragment's row replay is then at most RT_ROWS - 1 add steps from the
     // nearest entry instead of up to 15.  Staged-varyings layout: three planes of floats (address = plane + 4 t: no multiply);
@@ -527,13 +418,11 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // PROG / BLEND / DT >= 0: every draw of the batch has that program / blend mode / depth test (compile-time state:
 // the switches fold away); -1 = read them from the draw at run time.
 // EARLYOUT: some draw of the batch uses BlendMode.None, whose row early-out (Rasterizer.cs:520-523) is applied per chunk.
-#if !defined(SWR_ABL_LDSBYTES) && !defined(SWR_ABL_VARY_ALIAS)
 // LDS is allocated in units of 1,280 B (tools/ubench/lds_occupancy.hip: 16 one-wave workgroups per CU up to 10,240 B, 18 up to 8,960 B,
 // 21 up to 7,680 B, 25 up to 6,400 B, 32 up to 5,120 B)
-static_assert(sizeof(WaveLdsC<false>) <= 10240 && sizeof(WaveLdsC<true>) <= 10240, "16 waves per CU need <= 10,240 B of LDS per wave");
-#endif
+static_assert(sizeof(WaveLdsC<false>) <= 10240 && sizeof(WaveLdsC<true>) <= 8960, "16 (18) waves per CU need <= 10,240 (8,960) B of LDS per wave");
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
-__global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 && PHONG)) ? 5 : SWR_RASTER_MINWAVES) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+__global__ __launch_bounds__(64, PHONG ? 5 : 4) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
     if (batch_poisoned(a.ctrl, a.seq)) return;
@@ -586,7 +475,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
         const float inv_w = 1.0f / (float)(a.fp.width - 1), inv_h = 1.0f / (float)(a.fp.height - 1);      // Rasterizer.cs:362-363
         return shade_debug_varyings(w0f, w1f, w2f, q4.w, q5.w, wc_clip, na, nb, nc, sx, sy, inv_w, inv_h);
     };
-    // part: 0 = everything, 1 = only the three uv rows (SWR_VARY_EARLY 3: requested ahead of the chain replay, the texel address hangs
+    // part: 0 = everything, 1 = only the three uv rows (requested ahead of the chain replay, the texel address hangs
     // on them), 2 = everything but the uv rows, which `V` already holds
     auto load_varyings = [&L, vout_rsrc](int t, bool fastdiv, int part = 0, TriVaryings V = TriVaryings()) {
         if (VG) {
@@ -679,13 +568,10 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
 
     // (A rolling batch -- the tail of a batch carried into the next one so that every chunk is full -- was built and measured
     //  twice: chunks -7.7 %, batches +19 %, kernel +4 %.  It lives in the history of this file, commit "Rolling batch ...".)
-#ifdef SWR_ABL_PAD
-    float pad0 = (float)lane, pad1 = pad0 + 1.0f, pad2 = pad0 + 2.0f, pad3 = pad0 + 3.0f;
-#endif
     DrawConsts dc = {};                    // per-draw constants of draw `dc_draw` (see DrawConsts)
     uint32_t dc_draw = 0xffffffffu;
     uint32_t batch_no = 0;
-    bool fast_draw = false;                // SWR_FAST_SHADE: the chunk's draw satisfies the per-draw conditions of shade_dust2_fast
+    bool fast_draw = false;                // the chunk's draw satisfies the per-draw conditions of shade_dust2_fast
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first BATCH survivors
         //      of the window are staged in LDS ----
@@ -832,7 +718,6 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
         SWR_WAVE_LDS_SYNC();
         // ---- fragment stream of the batch, 64 at a time ----
         int t0 = 0;                                     // pairs that start at or before fragment `pos`, minus one
-#ifndef SWR_NO_HEAD_PREFETCH
         // The first two links of the lookup's dependent chain are taken off the chunk's critical path by running them one chunk
         // ahead: the three head words of the next window are fetched as soon as this chunk's cut is known, and between this
         // chunk's chain replay and its shading each lane's next pair is computed from them and that pair's word prefix counts
@@ -849,42 +734,23 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
             pre_n = __float_as_uint(L.stage[3][t_n].w);
         };
         lookup_ahead(0);
-#endif
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
             const unsigned long long validmask = SWR_BALLOT(g < total);
             // pair of fragment g = number of head bits below position g: a 64-bit window of the bitmap at `pos`
             const int hs = pos & 31;
-#ifndef SWR_NO_HEAD_PREFETCH
             const uint32_t h0 = hn0, h1 = hn1, h2 = hn2;
-#else
-            const int hw = pos >> 5;
-            const uint32_t h0 = L.head[hw], h1 = L.head[hw + 1], h2 = L.head[hw + 2];
-#endif
             const uint32_t win_lo = __builtin_amdgcn_alignbit(h1, h0, hs), win_hi = __builtin_amdgcn_alignbit(h2, h1, hs);
-#ifndef SWR_NO_HEAD_PREFETCH
             const int t = t_n;
-#else
-            const int t = t0 + (int)__builtin_amdgcn_mbcnt_hi(win_hi, __builtin_amdgcn_mbcnt_lo(win_lo, 0u));
-#endif
             const float4 f0 = L.stage[0][t], f1 = L.stage[1][t], f2 = L.stage[2][t], f3 = L.stage[3][t];
             TriVaryings Vg = TriVaryings();
-            if (VG && SWR_VARY_EARLY == 1) { if (valid) Vg = load_varyings(t, (__float_as_uint(f1.w) & SWR_FLAG_FASTDIV) != 0u); }
-#ifndef SWR_NO_HEAD_PREFETCH
             int k = valid ? g - (int)pre_n : 0;
-#else
-            int k = valid ? g - (int)__float_as_uint(f3.w) : 0;
-#endif
             // k-th covered pixel of pair t in row-major order: the mask word by a 16-bit-field compare against the
             // word prefix counts, then a 5-level selection inside the word
             int pix;
             {
-#ifndef SWR_NO_HEAD_PREFETCH
                 const uint4 wp = wp_n;
-#else
-                const uint4 wp = *reinterpret_cast<const uint4*>(&L.wpre[t][0]);
-#endif
                 const uint32_t kk = ((uint32_t)k | ((uint32_t)k << 16)) | 0x80008000u;
                 const int nle = __popc((kk - wp.x) & 0x80008000u) + __popc((kk - wp.y) & 0x80008000u) +
                                 __popc((kk - wp.z) & 0x80008000u) + __popc((kk - wp.w) & 0x80008000u);    // fields <= k, >= 1
@@ -905,13 +771,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     if (!simple) posw = kth_set_bit32(wsel, okk ? kw : 0);
                 }
                 pix = (wi * 32 + posw) & 255;
-#ifdef SWR_ABL_NOSELECT2      // tools/ablate.py timing experiments only (wrong image by design)
-                pix = (wi * 32 + kw) & 255;
-#endif
             }
-#ifdef SWR_ABL_NOSELECT
-            pix = k & 255;
-#endif
             // What the replay and the depth test will read from LDS depends on the pixel only: requested here, for every lane,
             // the reads return while the election's atomic is on its way (inside `if (act)` below they would be one more
             // dependent round trip; the compiler may not move them across the atomic itself).  The tile is as the previous chunk
@@ -960,23 +820,11 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                 t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
             }
             const bool act = lane < cut;
-            if (VG && SWR_VARY_EARLY == 2) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u); }
-            if (VG && SWR_VARY_EARLY == 3) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 1); }
-#ifndef SWR_NO_HEAD_PREFETCH
+            if (VG) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 1); }
             {   // (the head array has two spare words behind the last position: reading past the batch's end is in bounds)
                 const int hw_next = (pos + cut) >> 5;
                 hn0 = L.head[hw_next]; hn1 = L.head[hw_next + 1]; hn2 = L.head[hw_next + 2];
             }
-#endif
-#ifdef SWR_ABL_PAD            // tools/ablate.py timing experiment: SWR_ABL_PAD extra VALU instructions per chunk (issue-slack probe)
-#pragma unroll
-#ifdef SWR_ABL_PAD_FMA
-            for (int i = 0; i < SWR_ABL_PAD / 4; ++i) { pad0 = __builtin_fmaf(pad0, 1.5f, pad1); pad1 = __builtin_fmaf(pad1, 0.25f, pad2);
-                                                        pad2 = __builtin_fmaf(pad2, 0.75f, pad3); pad3 = __builtin_fmaf(pad3, 1.25f, pad0); }
-#else
-            for (int i = 0; i < SWR_ABL_PAD / 4; ++i) { pad0 = pad0 * 1.5f; pad1 = pad1 + 0.25f; pad2 = pad2 * 0.75f; pad3 = pad3 + 1.25f; }
-#endif
-#endif
 #ifdef SWR_DEBUG_COUNTERS
             ++dbg_chunks; dbg_chunk_lanes += (unsigned)cut;
 #endif
@@ -984,9 +832,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
             const DrawParams* __restrict__ cdp = a.draws + draw0;
             if (draw0 != dc_draw) {                                                       // wave-uniform: the constants live in SGPRs across chunks
                 dc_draw = draw0; dc = load_draw_consts(cdp);
-#if SWR_FAST_SHADE
                 if (!PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG) fast_draw = dust2_fast_applies(dc);
-#endif
             }
             const int f_program = PROG >= 0 ? PROG : dc.program, f_blend = BLEND >= 0 ? BLEND : dc.blend, f_dt = DT >= 0 ? DT : dc.depth_test;
             // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
@@ -1012,11 +858,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     // replay of the reference's add chain from the pair's first pixel: rows first, then columns
                     float w0 = f0.x, w1 = f0.y, w2 = f0.z;
                     const float inv_area = f0.w;
-#ifdef SWR_ABL_NOREPLAY
-                    const int nrow = 0, ncol = 0; asm volatile("" :: "v"(fs));
-#else
                     const int nrow = (pix >> 4) - (int)(fs >> 8), ncol = (pix & 15) - (int)(fs & 0xffu);
-#endif
 #ifdef SWR_DEBUG_COUNTERS
                     dbg_nrow = nrow; dbg_ncol = ncol;
 #endif
@@ -1033,9 +875,7 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }
             }
-#ifndef SWR_NO_HEAD_PREFETCH
             lookup_ahead(pos + cut);           // all lanes; its LDS reads return during the shading below
-#endif
             if (act) {
                 if (!EARLYOUT) {
                     if (depth_func(f_dt, d, z_old)) {                                                      // :505 / :318
@@ -1045,9 +885,8 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
                         float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
-                        constexpr bool FAST = SWR_FAST_SHADE && !PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG;
-                        const TriVaryings Vs = (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
-                                               (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u);
+                        constexpr bool FAST = !PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG;
+                        const TriVaryings Vs = VG ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u);
                         bool need_exact = !(FAST && fast_draw);           // wave-uniform
                         if (FAST && fast_draw) {
                             // speculate: the straight-line shader; verify: every shaded lane of the chunk took only legal shortcuts
@@ -1072,8 +911,8 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
                     if (e_pass) {
                         e_src = (PHONG && PROG == SWR_PROG_DEBUG_VARYINGS) ? shade_debug(t, w0f, w1f, w2f) :
                                 shade_fragment<PHONG>(cdp, dc, f_program, f_interp,
-                                                      (VG && SWR_VARY_EARLY == 3) ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) :
-                                                      (VG && SWR_VARY_EARLY != 0) ? Vg : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u), w0f, w1f, w2f);
+                                                      VG ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u),
+                                                      w0f, w1f, w2f);
                         e_alpha = is_line ? (e_src.w != 0.0f) : (e_src.w > 0.0f);
                     }
                 }
@@ -1148,9 +987,6 @@ __global__ __launch_bounds__(64, (SWR_VARY_GLOBAL == 1 || (SWR_VARY_GLOBAL == 2 
     n_tested = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_tested, lane), 63);
     n_shaded = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_shaded, lane), 63);
     n_written = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_written, lane), 63);
-#ifdef SWR_ABL_PAD
-    if (pad0 + pad1 + pad2 + pad3 == 12345.678f) n_tested += 1u;      // keeps the padding alive
-#endif
     if (lane == 0) a.tile_work[tile] = n_tested;            // the next flush's scheduling weight (k_scan_apply)
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;

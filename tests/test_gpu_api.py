@@ -390,7 +390,7 @@ def test_tile_list_overflow_poisons_the_batch_and_is_replayed_exactly(monkeypatc
     from oracle.binding import OracleRenderer
     from softwarerenderer_amd import Device
     monkeypatch.setenv("SWR_DEBUG_FILL_CAPACITY", "500")
-    dev = Device(0)
+    dev = Device(0, lib="libswr_hip_test.so")        # the hook exists in the test build only (-DSWR_TEST_HOOKS): the product reads no such variable
     monkeypatch.delenv("SWR_DEBUG_FILL_CAPACITY")
     try:
         scene = scenes.cfg3(320, 240, (3, 3), (20, 14), tex_size=64, seed=21)
@@ -411,7 +411,7 @@ def test_tile_list_overflow_poisons_the_batch_and_is_replayed_exactly(monkeypatc
 
 
 def test_more_than_2_pow_20_tiles_is_refused_not_overrun(device):
-    """the tile-count scan holds 1024 x 1024 tiles; a larger unbanded target used to write past the block sums.
+    """the tile-count scan holds 4096 block sums of 256 tiles; a larger unbanded target used to write past the block sums.
     Now the draw is refused (SWR_ERR_UNSUPPORTED) and the same target renders in tile-row bands."""
     from softwarerenderer_amd._native import SwrError, SWR_ERR_UNSUPPORTED
     scene = scenes.cfg1()

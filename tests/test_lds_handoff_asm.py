@@ -25,11 +25,13 @@ def kernels(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc on this machine")
     out = tmp_path_factory.mktemp("asm")
-    flags = ["-O3", "-fno-slp-vectorize", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-             "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", "-I" + os.path.join(ROOT, "include"),
-             "-I" + CSRC, "--cuda-device-only", "-S"]
+    # the product build's own flags, from its Makefile (`make print-flags`): an optimisation level, -fno-slp-vectorize or a new -m flag
+    # changed there changes the code checked here; only the link step's flags are dropped
+    mk = subprocess.run(["make", "-s", "-C", CSRC, "print-flags"], check=True, capture_output=True, text=True).stdout.split()
+    flags = [f for f in mk if f != "-shared" and not f.startswith("-Wl,")] + ["--cuda-device-only", "-S"]
+    assert "-O3" in flags and "-ffp-contract=off" in flags and "--offload-arch=gfx950" in flags, flags
     asm = os.path.join(out, "swr_api.s")
-    subprocess.run([HIPCC] + flags + [os.path.join(CSRC, "swr_api.hip"), "-o", asm], check=True, capture_output=True)
+    subprocess.run([HIPCC] + flags + ["swr_api.hip", "-o", asm], check=True, capture_output=True, cwd=CSRC)
     text = open(asm).read()
     found = {}
     for m in re.finditer(r"^(_ZN3swr(?:10k_raster_c|7k_cover)\w+):", text, flags=re.M):
