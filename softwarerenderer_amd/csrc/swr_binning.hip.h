@@ -385,7 +385,7 @@ __device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot,
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(256, 8) void k_bin(BinArgs a) {       // (8 waves per SIMD = 64 VGPRs: beside the raster kernel, swr_device.h)
+__global__ __launch_bounds__(256) void k_bin(BinArgs a) {
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && batch_poisoned(a.ctrl, a.seq)) return;
