@@ -115,7 +115,8 @@ typedef struct swr_mesh swr_mesh;
 typedef struct swr_texture swr_texture;
 
 int  swr_abi_version(void);
-/* Identity of this build: "hipcc=<compiler version>; csrc_sha256=<hash of the kernel sources>; fma=<0|1>; dot=<0|1|2>".
+/* Identity of this build: "hipcc=<compiler version>; csrc_sha256=<hash of the kernel sources>; fma=<0|1>; dot=<0|1|2>; extra=<extra
+ * compile switches, empty for the product>".
  * The lane-to-lane LDS hand-offs of k_cover / k_raster_c are verified per compiler + source pair: the
  * pair the parity sweeps ran on is committed in profiles/verified_build.json and tests/test_gpu_api.py compares. */
 const char* swr_build_info(void);
@@ -244,6 +245,9 @@ int  swr_is_sphere_in_frustum(swr_context* ctx, const float center_radius[4], co
                               const float projection[16], int* inside);
 /* `if (!IsSphereInFrustum(mesh.SphereBounds, ...)) return; RenderMesh(...)` of Renderer.cs:446-459, with the test
  * evaluated on the device at flush time (one thread per draw): a culled mesh costs no host round trip */
+/* LIMIT (ABI 3, all three render calls): one draw holds fewer than 2^26 vertex-stage records = vertices + 4 x triangles (about
+ * 16.7 M triangles of a u16-indexed mesh); a larger one is refused with SWR_ERR_UNSUPPORTED when it is recorded.  Draws are batched
+ * up to that same bound and flushed by themselves beyond it. */
 int  swr_render_mesh_culled(swr_context* ctx, const swr_mesh* mesh,
                             const float model[16], const float view[16], const float projection[16],
                             int program, const swr_uniforms* uniforms, const swr_texture* texture,

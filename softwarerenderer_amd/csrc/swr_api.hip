@@ -42,6 +42,7 @@ struct swr_mesh {
     swr_vertex* d_verts = nullptr;
     uint16_t* d_idx = nullptr;
     int n_verts = 0, n_idx = 0;
+    size_t cap_verts = 0, cap_idx = 0;        // bytes allocated behind d_verts / d_idx (a recycled transient mesh may hold more than it uses)
     bool transient = false;
     float box_lo[3] = { 0, 0, 0 }, box_hi[3] = { 0, 0, 0 };   // exact model-space AABB of the vertices (host, at creation)
     bool has_box = false;
@@ -137,7 +138,10 @@ struct swr_context {
 
     std::vector<DrawCmd> draws;
     uint64_t pend_verts = 0, pend_tris = 0;
-    std::vector<swr_mesh*> garbage;           // transient meshes to free at the next sync point
+    std::vector<swr_mesh*> garbage;           // transient meshes no recorded draw needs any more, possibly still read by kernels in flight
+    std::vector<swr_mesh*> mesh_pool;         // transient meshes whose batches are KNOWN to be complete: their device buffers are handed to the
+    size_t mesh_pool_bytes = 0;               // next swr_render_mesh_arrays call instead of hipFree / hipMalloc (both synchronise the device)
+    uint64_t stale_dropped[2] = { 0, 0 };     // present tickets dropped by back-pressure whose pixels predate a replay (swr_present_wait reports them)
     std::vector<Batch> inflight;              // launched optimistically, not yet validated
     uint32_t next_seq = 1;
     bool sync_flush = false;                  // SWR_SYNC_FLUSH=1: read the pair total back in every flush
@@ -323,14 +327,32 @@ void collect_spans(swr_context* c) {      // stream must be idle
     c->spans.clear();
 }
 
-void free_garbage(swr_context* c) {       // stream must be idle
-    for (swr_mesh* m : c->garbage) {
-        if (m->d_verts) (void)hipFree(m->d_verts);
-        if (m->d_idx) (void)hipFree(m->d_idx);
-        if (m->d_bounds) (void)hipFree(m->d_bounds);
-        delete m;
+void destroy_mesh(swr_mesh* m) {
+    if (m->d_verts) (void)hipFree(m->d_verts);
+    if (m->d_idx) (void)hipFree(m->d_idx);
+    if (m->d_bounds) (void)hipFree(m->d_bounds);
+    delete m;
+}
+// A transient mesh (swr_render_mesh_arrays: the reference's RenderMesh(vertices, indices, ...) makes one per call) whose batch is
+// complete goes to the pool, not to hipFree: freeing synchronises the whole device, which is exactly what an asynchronous present
+// loop must not do, and the next call with arrays of that size needs the same buffers again.
+const size_t kMeshPoolBytes = (size_t)1 << 30;
+void pool_mesh(swr_context* c, swr_mesh* m) {
+    c->mesh_pool.push_back(m);
+    c->mesh_pool_bytes += m->cap_verts + m->cap_idx;
+}
+void trim_mesh_pool(swr_context* c) {      // streams must be idle (hipFree): keep the newest meshes up to the byte budget
+    while (c->mesh_pool_bytes > kMeshPoolBytes && !c->mesh_pool.empty()) {
+        swr_mesh* m = c->mesh_pool.front();
+        c->mesh_pool.erase(c->mesh_pool.begin());
+        c->mesh_pool_bytes -= m->cap_verts + m->cap_idx;
+        destroy_mesh(m);
     }
+}
+void free_garbage(swr_context* c) {       // streams must be idle: nothing in flight reads the garbage any more
+    for (swr_mesh* m : c->garbage) pool_mesh(c, m);
     c->garbage.clear();
+    trim_mesh_pool(c);
 }
 
 int validate_locked(swr_context* c);
@@ -651,7 +673,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     const uint64_t spt = b.wireframe ? 6 : 2;        // primitive slots per submitted triangle
     // (V + 4 T vertex records of 64 B: k_raster_c addresses them with 32-bit byte offsets)
     if (V + 4 * T >= (1ull << 26) || spt * T >= 0xffffffffull)
-        return fail(c, SWR_ERR_UNSUPPORTED, "batch too large: flush more often");
+        return fail(c, SWR_ERR_UNSUPPORTED, "internal error: a batch beyond 2^26 vertex-stage records reached execute_batch (record_draw flushes before)");
     if (T == 0) return run_clear(c, b, cc, cd, b.clear_rgba);
     const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->band_tile_rows;
     // the per-tile scan (k_scan_sums / k_scan_apply) holds 4096 block sums of SWR_SCAN_BLOCK = 256 tiles each
@@ -748,8 +770,10 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     return SWR_OK;
 }
 
-void retire_batch(swr_context* c, Batch& b) {
-    for (auto& d : b.draws) if (d.mesh && d.mesh->transient) c->garbage.push_back(d.mesh);
+// complete = the batch's kernels are known to have finished (the stream was drained, or an event behind them has been waited for)
+void retire_batch(swr_context* c, Batch& b, bool complete = false) {
+    for (auto& d : b.draws)
+        if (d.mesh && d.mesh->transient) { if (complete) pool_mesh(c, d.mesh); else c->garbage.push_back(d.mesh); }
     b.draws.clear();
 }
 
@@ -778,15 +802,18 @@ int validate_locked(swr_context* c) {
         c->totals.flushes += 0;
         c->replays++;
         for (auto& b : todo) {
-            if (!rc && b.seq >= h.first_bad)
+            if (!rc && b.seq >= h.first_bad) {
                 rc = execute_batch(c, b, MODE_SYNC, b.seq != h.first_bad);   // the first bad batch already counted its triangles
-            retire_batch(c, b);
+                retire_batch(c, b);                                         // (replayed: its kernels are in flight again)
+            } else {
+                retire_batch(c, b, true);
+            }
         }
         if (!rc) rc = drain_streams(c);
         if (!rc) rc = check_list_overflow(c);
         return rc;
     }
-    for (auto& b : c->inflight) retire_batch(c, b);
+    for (auto& b : c->inflight) retire_batch(c, b, true);
     c->inflight.clear();
     return check_list_overflow(c);
 }
@@ -907,6 +934,10 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     const int n_tris = mesh->n_idx / 3;                             // Rasterizer.cs:180
     if (n_tris == 0) return SWR_OK;
     if (band_rejects(c, mesh, model, view, proj)) return SWR_OK;      // nothing of it can land in this band
+    // one batch holds fewer than 2^26 vertex-stage records (one per vertex + four per triangle for the clipper: k_raster_c addresses
+    // them with 32-bit byte offsets); a batch of several draws is flushed in time below, a SINGLE draw beyond it cannot be helped
+    if ((uint64_t)mesh->n_verts + 4 * (uint64_t)n_tris >= (1ull << 26))
+        return fail(c, SWR_ERR_UNSUPPORTED, "mesh exceeds 2^26 vertex-stage records (vertices + 4 x triangles: about 16.7 M triangles): split it");
     // keep a batch within the 32-bit slot / vertex numbering
     // (and the vertex-stage output -- one record per vertex plus four per triangle for the clipper -- below 4 GiB)
     if (c->pend_verts + (uint64_t)mesh->n_verts + 4 * (c->pend_tris + (uint64_t)n_tris) >= (1ull << 26)) {
@@ -942,7 +973,22 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
     const int used = (ni / 3) * 3;
     for (int i = 0; i < used; ++i)
         if ((int)idx[i] >= nv) return fail(c, SWR_ERR_INVALID_ARG, "index out of range (C#: IndexOutOfRangeException)");
-    swr_mesh* m = new swr_mesh();
+    swr_mesh* m = nullptr;
+    if (transient) {                               // smallest pooled mesh whose buffers hold these arrays
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < c->mesh_pool.size(); ++i) {
+            swr_mesh* q = c->mesh_pool[i];
+            if (q->cap_verts >= (size_t)nv * sizeof(swr_vertex) && q->cap_idx >= (size_t)ni * 2 + 8 &&
+                (best == (size_t)-1 || q->cap_verts + q->cap_idx < c->mesh_pool[best]->cap_verts + c->mesh_pool[best]->cap_idx)) best = i;
+        }
+        if (best != (size_t)-1) {
+            m = c->mesh_pool[best];
+            c->mesh_pool.erase(c->mesh_pool.begin() + (std::ptrdiff_t)best);
+            c->mesh_pool_bytes -= m->cap_verts + m->cap_idx;
+            m->bounds_ready = false; m->has_box = false;
+        }
+    }
+    if (!m) m = new swr_mesh();
     m->n_verts = nv; m->n_idx = ni; m->transient = transient;
     if (nv > 0) {                                  // exact AABB (min / max only): input to band_rejects
         bool ok = true;
@@ -956,19 +1002,34 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
         m->has_box = ok;
     }
     hipError_t e = hipSuccess;
-    if (nv) e = hipMalloc((void**)&m->d_verts, (size_t)nv * sizeof(swr_vertex));
-    if (e == hipSuccess && ni) e = hipMalloc((void**)&m->d_idx, (size_t)ni * 2 + 8);
+    if (nv && m->cap_verts < (size_t)nv * sizeof(swr_vertex)) {
+        e = hipMalloc((void**)&m->d_verts, (size_t)nv * sizeof(swr_vertex));
+        if (e == hipSuccess) m->cap_verts = (size_t)nv * sizeof(swr_vertex);
+    }
+    if (e == hipSuccess && ni && m->cap_idx < (size_t)ni * 2 + 8) {
+        e = hipMalloc((void**)&m->d_idx, (size_t)ni * 2 + 8);
+        if (e == hipSuccess) m->cap_idx = (size_t)ni * 2 + 8;
+    }
     // (only front-end kernels read a mesh: the upload goes to their stream, so a pipelined frame does not wait for the raster stream)
     if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, front_stream_of(c));
     if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, front_stream_of(c));
     if (e != hipSuccess) {
-        if (m->d_verts) (void)hipFree(m->d_verts);
-        if (m->d_idx) (void)hipFree(m->d_idx);
-        delete m;
+        destroy_mesh(m);
         c->err = std::string("mesh upload failed: ") + hipGetErrorString(e);
         return e == hipErrorOutOfMemory ? SWR_ERR_OOM : SWR_ERR_HIP;
     }
     *out = m;
+    return SWR_OK;
+}
+
+// Were the pixels of present slot `slot` rendered by a batch that has to be replayed?  Only if a batch flushed at or before that
+// present poisoned itself: Ctrl::first_bad (one small blocking copy, and only when the pinned poison word is up at all).
+int present_is_stale(swr_context* c, int slot, bool& stale) {
+    stale = false;
+    if (!*(volatile uint32_t*)c->host_poison) return SWR_OK;
+    Ctrl h;
+    SWR_HIP(c, hipMemcpy(&h, c->d_ctrl.p, sizeof h, hipMemcpyDeviceToHost));
+    stale = h.first_bad <= c->present_seq[slot];
     return SWR_OK;
 }
 
@@ -989,10 +1050,13 @@ int swr_abi_version(void) { return SWR_ABI_VERSION; }
 #ifndef SWR_BUILD_SRC_SHA
 #define SWR_BUILD_SRC_SHA "unknown"
 #endif
+#ifndef SWR_BUILD_EXTRA
+#define SWR_BUILD_EXTRA ""
+#endif
 #define SWR_STR2(x) #x
 #define SWR_STR(x) SWR_STR2(x)
 const char* swr_build_info(void) {
-    return "hipcc=" SWR_BUILD_HIPCC "; csrc_sha256=" SWR_BUILD_SRC_SHA "; fma=" SWR_STR(SWR_NUMERICS_FMA) "; dot=" SWR_STR(SWR_DOT_PAIRWISE);
+    return "hipcc=" SWR_BUILD_HIPCC "; csrc_sha256=" SWR_BUILD_SRC_SHA "; fma=" SWR_STR(SWR_NUMERICS_FMA) "; dot=" SWR_STR(SWR_DOT_PAIRWISE) "; extra=" SWR_BUILD_EXTRA;
 }
 
 int swr_numerics_mode(int* fma, int* dot_order) {
@@ -1070,6 +1134,8 @@ void swr_destroy(swr_context* c) {
     c->inflight.clear();
     collect_spans(c);
     free_garbage(c);
+    for (swr_mesh* m : c->mesh_pool) destroy_mesh(m);
+    c->mesh_pool.clear();
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     for (auto& fs : c->slots) { if (fs.host) (void)hipHostFree(fs.host); if (fs.done) (void)hipEventDestroy(fs.done); }
     if (c->host_poison) (void)hipHostFree(c->host_poison);
@@ -1248,7 +1314,15 @@ int swr_present_rgb_async(swr_context* c, float* rgb, uint64_t* ticket) {
     }
     // the slot's previous copy (two presents ago) must be over before its staging buffer is overwritten: back-pressure, not
     // steady-state waiting -- a caller that waits for ticket i before it presents frame i + 2 never blocks here
-    if (c->present_ticket[slot]) { SWR_HIP(c, hipEventSynchronize(c->present_done[slot])); c->present_ticket[slot] = 0; }
+    if (c->present_ticket[slot]) {
+        SWR_HIP(c, hipEventSynchronize(c->present_done[slot]));
+        // the ticket is dropped unwaited: if a batch at or before that present poisoned itself, its pixels were stale -- remember it
+        // for the swr_present_wait that may still come
+        bool stale = false;
+        if ((rc = present_is_stale(c, slot, stale))) return rc;
+        if (stale) c->stale_dropped[slot] = c->present_ticket[slot];
+        c->present_ticket[slot] = 0;
+    }
     if (n) {
         if (c->present_buf[slot].cap < n * 12) {
             // growing frees the old block: make sure neither stream still uses it (first frame / after a resize only)
@@ -1273,21 +1347,30 @@ int swr_present_wait(swr_context* c, uint64_t ticket) {
     SWR_ENTER(c);
     int slot = -1;
     for (int i = 0; i < 2; ++i) if (c->present_ticket[i] == ticket && ticket) slot = i;
-    if (slot < 0) return ticket && ticket <= c->next_ticket ? SWR_OK : fail(c, SWR_ERR_INVALID_ARG, "unknown present ticket");   // already waited for
+    if (slot < 0) {
+        if (!ticket || ticket > c->next_ticket) return fail(c, SWR_ERR_INVALID_ARG, "unknown present ticket");
+        for (int i = 0; i < 2; ++i)
+            if (c->stale_dropped[i] == ticket) { c->stale_dropped[i] = 0; return SWR_STALE; }     // dropped by back-pressure, and it was stale
+        return SWR_OK;                                                                             // already waited for
+    }
     SWR_HIP(c, hipEventSynchronize(c->present_done[slot]));
     c->present_ticket[slot] = 0;
-    if (*(volatile uint32_t*)c->host_poison) {
-        // a batch did not fit its pair buffers and poisoned itself (and everything after it): the copied pixels predate it.
-        // Drain, replay (validate_locked) and tell the caller to present again.
-        int rc = sync_locked(c);
+    bool stale = false;
+    int rc = present_is_stale(c, slot, stale);
+    if (rc) return rc;
+    if (stale) {
+        // a batch flushed at or before this present did not fit its pair buffers and poisoned itself (and everything after it): the
+        // copied pixels predate it.  Drain, replay (validate_locked) and tell the caller to present again.
+        rc = sync_locked(c);
         return rc ? rc : SWR_STALE;
     }
-    // every batch flushed before this present has completed (the flatten ran behind them): retire them without draining the stream
+    // Every batch flushed before this present has completed (the flatten ran behind them): retire them without draining the stream,
+    // and without freeing anything -- their transient meshes go to the pool (hipFree would wait for frame i + 1, which is rendering).
+    // (A batch poisoned AFTER this present leaves this frame good: it is replayed at the next synchronisation point.)
     const uint32_t upto = c->present_seq[slot];
     size_t k = 0;
-    while (k < c->inflight.size() && c->inflight[k].seq <= upto) { retire_batch(c, c->inflight[k]); ++k; }
+    while (k < c->inflight.size() && c->inflight[k].seq <= upto) { retire_batch(c, c->inflight[k], true); ++k; }
     c->inflight.erase(c->inflight.begin(), c->inflight.begin() + (std::ptrdiff_t)k);
-    free_garbage(c);
     return SWR_OK;
 }
 

@@ -577,7 +577,8 @@ def test_build_identity_matches_the_verified_pair():
         pytest.skip("development A/B build (tools/ab/*.sh): the verified pair is recorded for the round's final build only")
     info = _native.load().swr_build_info().decode()
     fields = dict(kv.split("=", 1) for kv in info.split("; "))
-    assert set(fields) == {"hipcc", "csrc_sha256", "fma", "dot"} and len(fields["csrc_sha256"]) == 64
+    assert set(fields) == {"hipcc", "csrc_sha256", "fma", "dot", "extra"} and len(fields["csrc_sha256"]) == 64
+    assert fields["extra"] == "", "an A/B variant (make EXTRA=...) sits in the product library's place: rebuild it"
     with open(os.path.join(ROOT, "profiles", "verified_build.json")) as f:
         ver = json.load(f)
     assert fields["hipcc"] == ver["hipcc"], "built with another compiler than the one the LDS hand-offs were verified with"
@@ -650,4 +651,140 @@ def test_asynchronous_present_reports_a_stale_frame_after_a_replay():
     t = r0.window.PresentAsync(out)                                   # the caller's reaction: present again
     assert r0.window.PresentWait(t) is True
     assert ulp_distance(out, rc[..., :3]).max() <= 1
+    r0.close(); r1.close(); dev.close()
+
+
+def test_overflow_replay_while_the_next_frames_front_end_is_already_running():
+    """with frames in flight the front end of flush N+1 runs beside the raster kernel of flush N, so a batch can poison
+    itself while an EARLIER batch is still rasterising and while LATER batches' front ends are queued or running.  Four order-dependent
+    frames back to back, no synchronisation in between: fits, fits (big: its raster kernel is long), does NOT fit, fits -- the bad one's
+    own kernels and every later batch must leave the framebuffer alone (batch_poisoned goes by first_bad, not by the sticky flag: the
+    running raster kernel of the good batch must finish ALL its tiles), and the host replays from the bad one exactly."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    dev = Device(0)
+    assert dev.pipelining() == 1                                   # the default
+    W = H = 512
+    sizing = scenes.cfg2(W, H, 2500, seed=70, min_area=100.0, max_area=4000.0)       # sizes the pair buffers (both sets)
+    good = scenes.cfg2(W, H, 2400, seed=71, min_area=100.0, max_area=4000.0)         # fits, and rasterises for a while
+    bad = scenes.state_scene(W, H, 9000, seed=72, blend=BlendMode.Additive)          # far more pairs than the buffers hold
+    after = scenes.state_scene(W, H, 900, seed=73, blend=BlendMode.Multiply)
+    for s_ in (bad, after):
+        s_.clear_color = None; s_.clear_depth = False              # accumulate: every frame's pixels depend on all frames before
+    o = OracleRenderer(W, H)
+    o.render_scene(sizing); o.render_scene(sizing); o.reset_stats()
+    o.render_scene(good); o.render_scene(bad)
+    rc, rd = o.render_scene(after)
+    rst = o.stats(); o.close()
+
+    r0 = scenes.SceneRenderer(dev, sizing)
+    r0.render(); r0.render()                                       # synchronous sizing, then one optimistic frame: both raster sets exist
+    dev.reset_stats()
+    rs = [scenes.SceneRenderer(dev, s_, window=r0.window) for s_ in (good, bad, after)]
+    replays = dev.replay_count()
+    for r in rs:
+        r.submit_frame(); dev.flush()                              # three flushes, the host never waits
+    c, d = r0.window._read()                                       # sync point: validate + replay from the bad batch
+    assert dev.replay_count() == replays + 1
+    st = dev.stats()
+    assert_frame_parity(c, d, rc, rd, 1, "replay with frames in flight")
+    for k in ("triangles_in", "triangles_setup", "fragments_tested", "fragments_shaded", "fragments_written"):
+        assert st[k] == rst[k], (k, st[k], rst[k])
+    # and the same sequence again on the grown buffers: no replay this time, same pixels
+    dev.reset_stats()
+    rs[0].submit_frame(); dev.flush(); rs[1].submit_frame(); dev.flush(); rs[2].submit_frame(); dev.flush()
+    o = OracleRenderer(W, H)
+    o.upload(rc, rd)
+    o.render_scene(good); o.render_scene(bad)
+    rc2, rd2 = o.render_scene(after); o.close()
+    c2, d2 = r0.window._read()
+    assert dev.replay_count() == replays + 1
+    assert_frame_parity(c2, d2, rc2, rd2, 1, "frames in flight, grown buffers")
+    for r in [r0] + rs:
+        r.close()
+    dev.close()
+
+
+def test_pipelining_modes_render_the_same_frames():
+    """swr_set_pipelining: frames in flight (1, default; 2 = front stream at default priority) and one stream (0) differ in scheduling
+    only -- a sequence of order-dependent frames gives the same words in every mode, and switching in the middle is safe."""
+    from softwarerenderer_amd import Device
+    dev = Device(0)
+    a = scenes.cfg3(640, 480, (3, 3), (30, 20), tex_size=64, seed=81)
+    b = scenes.state_scene(640, 480, 1500, seed=82, blend=BlendMode.Alpha)
+    b.clear_color = None; b.clear_depth = False
+    ra = scenes.SceneRenderer(dev, a)
+    rb = scenes.SceneRenderer(dev, b, window=ra.window)
+    frames = {}
+    for mode in (1, 0, 2, 1):
+        dev.set_pipelining(mode)
+        assert dev.pipelining() == mode
+        for _ in range(3):
+            ra.submit_frame(); dev.flush(); rb.submit_frame(); dev.flush()
+        c, d = ra.window._read()
+        frames.setdefault("c", c); frames.setdefault("d", d)
+        assert np.array_equal(c.view(np.uint32), frames["c"].view(np.uint32)) and np.array_equal(d.view(np.uint32), frames["d"].view(np.uint32)), mode
+    with pytest.raises(Exception):
+        dev.set_pipelining(3)
+    ra.close(); rb.close(); dev.close()
+
+
+def test_present_loop_over_array_draws_never_waits_for_the_next_frame():
+    """swr_render_mesh_arrays -- the reference's RenderMesh(vertices, indices, ...) -- makes a transient mesh per
+    call; swr_present_wait used to hipFree the retired ones, which synchronises the device, i.e. waits for frame i + 1.  Now they are
+    recycled: a present loop over array draws allocates nothing in steady state, never drains (swr_sync_count stays), and every
+    delivered frame is exact."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    dev = Device(0)
+    scene = scenes.cfg3(384, 256, (2, 2), (24, 16), tex_size=64, seed=93)
+    o = OracleRenderer(scene.width, scene.height)
+    rc, _ = o.render_scene(scene); o.close()
+    r = scenes.SceneRenderer(dev, scene, retained=False)            # every draw goes through swr_render_mesh_arrays
+    outs = [np.zeros((scene.height, scene.width, 3), dtype=np.float32) for _ in range(2)]
+    for a in outs:
+        dev.pin(a)
+    r.submit_frame(); t_prev = r.window.PresentAsync(outs[0])       # frame 0 (synchronous sizing happens here)
+    r.submit_frame(); t_cur = r.window.PresentAsync(outs[1])
+    assert r.window.PresentWait(t_prev) is True
+    syncs = dev.sync_count()
+    for i in range(2, 14):
+        r.submit_frame()
+        t_next = r.window.PresentAsync(outs[i & 1])                 # overwrites the buffer whose ticket was waited for last round
+        assert r.window.PresentWait(t_cur) is True                  # frame i - 1 arrives while frame i renders
+        assert ulp_distance(outs[(i - 1) & 1], rc[..., :3]).max() <= 1
+        t_cur = t_next
+    assert r.window.PresentWait(t_cur) is True
+    assert dev.sync_count() == syncs                                # nothing in the loop drained the stream (or freed: frees drain)
+    for a in outs:
+        dev.unpin(a)
+    r.close(); dev.close()
+
+
+def test_a_frame_presented_before_a_later_overflow_is_not_reported_stale():
+    """ADVICE r3: SWR_STALE goes by WHICH batch poisoned itself (Ctrl::first_bad against the batches the present covers), not by the
+    global flag: frame A is presented, frame B (flushed after the present) overflows -- A's pixels are good and must be delivered
+    as such; B is replayed at the next synchronisation point."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    dev = Device(0)
+    small = scenes.cfg2(256, 256, 60, seed=64, min_area=10.0, max_area=80.0)
+    big = scenes.cfg2(256, 256, 3000, seed=65, min_area=200.0, max_area=9000.0)
+    o = OracleRenderer(256, 256)
+    ra_, _ = o.render_scene(small)
+    rb_, rbd = o.render_scene(big)
+    o.close()
+    r0 = scenes.SceneRenderer(dev, small)
+    r0.render()                                                       # synchronous sizing (small buffers)
+    r1 = scenes.SceneRenderer(dev, big, window=r0.window)
+    out = np.zeros((256, 256, 3), dtype=np.float32)
+    before = dev.replay_count()
+    r0.submit_frame()
+    t = r0.window.PresentAsync(out)                                   # frame A: fits
+    r1.submit_frame(); dev.flush()                                    # frame B: flushed AFTER the present, does not fit
+    assert r0.window.PresentWait(t) is True                           # A is good: not stale, no replay forced here
+    assert ulp_distance(out, ra_[..., :3]).max() <= 1
+    c, d = r0.window._read()                                          # sync point: B is replayed now
+    assert dev.replay_count() == before + 1
+    assert_frame_parity(c, d, rb_, rbd, 1, "late overflow")
     r0.close(); r1.close(); dev.close()
