@@ -71,8 +71,9 @@ def main():
                     help="torch.distributed backend; gloo (control plane only, needs --gather p2p) rehearses the N>1 path with "
                          "several ranks on ONE GPU (SWR_BENCH_ONE_DEVICE=1), which RCCL refuses")
     ap.add_argument("--pipelining", type=int, choices=[0, 1, 2], default=1,
-                    help="frames in flight inside the library (swr_set_pipelining): 1 (default) = the front end of frame i+1 runs on a second "
-                         "stream beside the raster kernel of frame i, 0 = one stream, 2 = as 1 with the front stream at default priority")
+                    help="frames in flight inside the library (swr_set_pipelining): 1 (the library's default) = frames of up to 2^15 tiles or batches "
+                         "of up to 2^17 triangles run their front end on a second stream beside the previous frame's raster kernel (cfg2: yes; "
+                         "cfg3 / cfg4 / cfg5: no -- measured zero-sum there), 0 = never, 2 = every batch")
     ap.add_argument("--camera-jitter", type=float, default=0.0,
                     help="perturb the view matrix of every frame on the host (a translation of this amplitude in view space plus a small "
                          "yaw, a different one each frame): the tile order feeds on the previous frame's fragment counts, this shows it is "

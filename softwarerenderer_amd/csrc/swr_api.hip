@@ -49,6 +49,7 @@ struct swr_mesh {
 };
 struct swr_texture {
     uint8_t* d_rgba = nullptr;
+    uint8_t* d_blocked = nullptr;             // block-linear copy (4 x 4-texel blocks of 64 B) for the bilinear filter, made when it is first switched on
     int w = 0, h = 0;
     bool bilinear = false;                    // build-defined extension; the reference's Texture.Sample is nearest
 };
@@ -67,6 +68,12 @@ enum Stage { ST_VERTEX = 0, ST_SETUP, ST_BIN, ST_SORT, ST_COVER, ST_RASTER, ST_C
 
 struct EventSpan { int stage; hipEvent_t a, b; };
 
+#ifndef SWR_TIMING_EVENT_FLAGS
+#define SWR_TIMING_EVENT_FLAGS hipEventDisableSystemFence
+#endif
+#ifndef SWR_HANDOVER_EVENT_FLAGS
+#define SWR_HANDOVER_EVENT_FLAGS hipEventDisableTiming
+#endif
 #define SWR_SLOTS 3
 struct FrameSlot { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool busy = false; };
 
@@ -111,8 +118,12 @@ struct swr_context {
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t front_stream = nullptr;    // front ends of pipelined flushes (and mesh uploads, which only front-end kernels read)
-    int pipelining = 1;                    // swr_set_pipelining: 0 off, 1 on (front stream at high priority), 2 on (normal priority: A/B)
-    int front_prio_mode = 0;               // pipelining mode the front stream was created for
+    int pipelining = 1;                    // swr_set_pipelining: 0 off, 1 auto (see execute_batch), 2 every batch
+    uint32_t pipeline_max_tris = 1u << 17; // mode 1: a batch is pipelined when it has at most this many triangles ...
+    uint32_t pipeline_max_tiles = 1u << 15;   // ... or the band at most this many tiles (8 raster waves per wave slot of the chip)
+    hipEvent_t f_tail_ev = nullptr, r_front_ev = nullptr;
+    bool f_tail_pending = false;           // the front stream carries work (a front end, a mesh upload) the raster stream has not been ordered behind
+    bool r_front_pending = false;          // an unpipelined batch ran its front end on the raster stream since the front stream last waited for it
     RasterSet sets[2];
     uint32_t raster_span_no = 0;           // profiling mode 3: raster launches seen since swr_profile_enable
     char dev_name[256] = { 0 };
@@ -287,7 +298,9 @@ FrameParams frame_params(const swr_context* c) {
 hipEvent_t get_event(swr_context* c) {
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    // timing only, never ordering: no system-scope fence (the default event's cache write-back / invalidation would hit the OTHER
+    // stream's kernels when frames are in flight -- measured: 20 timed frames 0.651 ms with default events, see SWR_EVENT_FLAGS)
+    if (hipEventCreateWithFlags(&e, SWR_TIMING_EVENT_FLAGS) != hipSuccess) (void)hipEventCreate(&e);
     return e;
 }
 struct ScopedSpan {
@@ -363,6 +376,7 @@ int drain_streams(swr_context* c) {
     SWR_HIP(c, hipStreamSynchronize(c->stream));
     if (c->front_stream) SWR_HIP(c, hipStreamSynchronize(c->front_stream));
     for (auto& s : c->sets) s.raster_pending = false;
+    c->f_tail_pending = c->r_front_pending = false;
     return SWR_OK;
 }
 
@@ -378,22 +392,26 @@ int sync_locked(swr_context* c) {
 }
 
 // the stream mesh uploads and front-end-only work go to: the front stream while frames are pipelined, else the context's stream
-hipStream_t front_stream_of(swr_context* c) { return (c->pipelining && c->front_stream) ? c->front_stream : c->stream; }
+hipStream_t front_stream_of(swr_context* c) {
+    if (c->pipelining && c->front_stream) { c->f_tail_pending = true; return c->front_stream; }
+    return c->stream;
+}
 
-// (re)creates the front stream for the current pipelining mode; streams must be idle
+// creates the front stream (once) and the hand-over events
 int ensure_front_stream(swr_context* c) {
     if (!c->pipelining) return SWR_OK;
-    if (c->front_stream && c->front_prio_mode == c->pipelining) return SWR_OK;
-    if (c->front_stream) { SWR_HIP(c, hipStreamSynchronize(c->front_stream)); SWR_HIP(c, hipStreamDestroy(c->front_stream)); c->front_stream = nullptr; }
+    if (c->front_stream) return SWR_OK;
     int least = 0, greatest = 0;
     SWR_HIP(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    // mode 1: the front end's short kernels go first wherever a slot frees up, the raster kernel (65,536 one-wave workgroups) fills the rest
+    // high priority: the front end's short kernels go first wherever a slot frees up, the raster kernel (65,536 one-wave workgroups)
+    // fills the rest (default priority measured the same within noise, profiles/r04_frames_in_flight.md)
     (void)least;
-    SWR_HIP(c, hipStreamCreateWithPriority(&c->front_stream, hipStreamNonBlocking, c->pipelining == 1 ? greatest : 0));      // 0 = the default priority
-    c->front_prio_mode = c->pipelining;
+    SWR_HIP(c, hipStreamCreateWithPriority(&c->front_stream, hipStreamNonBlocking, greatest));
+    SWR_HIP(c, hipEventCreateWithFlags(&c->f_tail_ev, hipEventDisableTiming));
+    SWR_HIP(c, hipEventCreateWithFlags(&c->r_front_ev, hipEventDisableTiming));
     for (auto& s : c->sets) {
-        if (!s.front_done) SWR_HIP(c, hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
-        if (!s.raster_done) SWR_HIP(c, hipEventCreateWithFlags(&s.raster_done, hipEventDisableTiming));
+        if (!s.front_done) SWR_HIP(c, hipEventCreateWithFlags(&s.front_done, SWR_HANDOVER_EVENT_FLAGS));
+        if (!s.raster_done) SWR_HIP(c, hipEventCreateWithFlags(&s.raster_done, SWR_HANDOVER_EVENT_FLAGS));
     }
     return SWR_OK;
 }
@@ -567,6 +585,11 @@ int bin_and_raster(swr_context* c, RasterSet& S, hipStream_t F, const Batch& b, 
         // hand-over: the raster kernel (context's stream) starts when this batch's front end is complete
         SWR_HIP(c, hipEventRecord(S.front_done, F));
         SWR_HIP(c, hipStreamWaitEvent(c->stream, S.front_done, 0));
+    } else if (c->pipelining && mode == MODE_ASYNC) {
+        // a batch that is NOT pipelined (too big to gain, see execute_batch) while others are: the next pipelined front end shares
+        // slot_tb / want / the lists with this one and may not start on the front stream before this point of the raster stream
+        SWR_HIP(c, hipEventRecord(c->r_front_ev, c->stream));
+        c->r_front_pending = true;
     }
     {
         ScopedSpan sp(c, ST_RASTER);
@@ -643,10 +666,33 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     // pipelined flushes alternate between the two RasterSets and run their front end on the front stream; a synchronous batch (the
     // first frame, a replay, SWR_SYNC_FLUSH) reads the pair total back half way and runs on the context's stream alone
     if ((rc = ensure_front_stream(c))) return rc;
-    const bool piped = mode == MODE_ASYNC && c->pipelining != 0;
+    // Which batches gain (profiles/r04_frames_in_flight.md).  A raster kernel holds every byte of LDS while it has tiles left to start,
+    // so a front-end block runs beside it only in the slot of a retiring raster wave, and what it takes there it takes from the raster
+    // kernel (measured zero-sum); the overlap that pays is in the raster kernel's TAIL and in the launch gaps and ramps of the short
+    // front-end kernels.  1920x1080 (8,160 tiles = two waves of tiles per wave slot): -8 ... -16 % from 32 k to 260 k triangles, still
+    // -5 % at 1 M; 4096x4096 / 1 M triangles (65,536 tiles: the tail is a sixteenth of the kernel): +-1 % in steady state, and a burst
+    // of N frames pays one un-overlapped front end to fill the pipe (+0.45 ms / N).  Mode 1 pipelines small frames OR small batches.
+    uint64_t n_tris_batch = 0;
+    for (auto& d : b.draws) n_tris_batch += d.p.n_tris;
+    const uint64_t n_tiles_band = (uint64_t)c->tiles_x * (uint64_t)c->band_tile_rows;
+    const bool piped = mode == MODE_ASYNC && (c->pipelining == 2 || (c->pipelining == 1 && (n_tris_batch <= c->pipeline_max_tris ||
+                                                                                            n_tiles_band <= c->pipeline_max_tiles)));
     RasterSet& S = c->sets[c->pipelining ? (b.seq & 1u) : 0u];
     const hipStream_t F = piped ? c->front_stream : c->stream;
-    if (c->pipelining && !piped) SWR_HIP(c, hipStreamSynchronize(c->front_stream));     // earlier front ends and mesh uploads
+    if (c->pipelining && mode != MODE_ASYNC) SWR_HIP(c, hipStreamSynchronize(c->front_stream));     // earlier front ends and mesh uploads
+    if (c->pipelining && mode == MODE_ASYNC) {
+        // stream-level ordering between the two places a front end can run (no host wait)
+        if (!piped && c->f_tail_pending) {
+            SWR_HIP(c, hipEventRecord(c->f_tail_ev, c->front_stream));
+            SWR_HIP(c, hipStreamWaitEvent(c->stream, c->f_tail_ev, 0));
+            c->f_tail_pending = false;
+        }
+        if (piped && c->r_front_pending) {
+            SWR_HIP(c, hipStreamWaitEvent(c->front_stream, c->r_front_ev, 0));
+            c->r_front_pending = false;
+        }
+        if (piped) c->f_tail_pending = true;
+    }
     const size_t nd = b.draws.size();
     std::vector<DrawParams> hp(nd);
     std::vector<BlockMap> vblocks, tblocks;
@@ -765,7 +811,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if (rc) return rc;
     // a synchronous batch ran its front end on the context's stream: the next pipelined front end shares slot_tb / want / the lists
     // with it, so it may not start before this one is over (rare path: the first frame and replays)
-    if (c->pipelining && !piped) SWR_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->pipelining && mode != MODE_ASYNC) SWR_HIP(c, hipStreamSynchronize(c->stream));
     if (cc || cd) return run_clear(c, b, cc, cd, b.clear_rgba);   // nothing was binned
     return SWR_OK;
 }
@@ -956,6 +1002,7 @@ int record_draw(swr_context* c, swr_mesh* mesh, const float* model, const float*
     d.p.verts = mesh->d_verts; d.p.idx = mesh->d_idx;
     d.p.tex = tex ? tex->d_rgba : nullptr;
     d.p.tex_w = tex ? tex->w : 0; d.p.tex_h = tex ? (tex->bilinear ? -tex->h : tex->h) : 0;
+    if (tex && tex->bilinear && tex->d_blocked) { d.p.tex = tex->d_blocked; d.p.tex_w = -tex->w; }      // (texture_fetch in swr_device.h)
     d.p.tex_wf = tex ? (float)tex->w : 0.0f; d.p.tex_hf = tex ? (float)tex->h : 0.0f;
     d.p.program = program; d.p.cull = cull; d.p.depth_test = depth_test; d.p.blend = blend;
     d.p.n_verts = (uint32_t)mesh->n_verts; d.p.n_tris = (uint32_t)n_tris;
@@ -1155,6 +1202,8 @@ void swr_destroy(swr_context* c) {
         if (s.raster_done) (void)hipEventDestroy(s.raster_done);
     }
     if (c->front_stream) (void)hipStreamDestroy(c->front_stream);
+    if (c->f_tail_ev) (void)hipEventDestroy(c->f_tail_ev);
+    if (c->r_front_ev) (void)hipEventDestroy(c->r_front_ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1248,7 +1297,7 @@ int swr_flush(swr_context* c) { SWR_ENTER(c); return flush_locked(c); }
 
 int swr_set_pipelining(swr_context* c, int mode) {
     SWR_ENTER(c);
-    if (mode < 0 || mode > 2) return fail(c, SWR_ERR_INVALID_ARG, "pipelining mode must be 0 (off), 1 (on) or 2 (on, front stream at normal priority)");
+    if (mode < 0 || mode > 2) return fail(c, SWR_ERR_INVALID_ARG, "pipelining mode must be 0 (off), 1 (frames of up to 2^15 tiles or batches of up to 2^17 triangles) or 2 (every batch)");
     if (mode == c->pipelining) return SWR_OK;
     int rc = flush_locked(c);
     if (rc) return rc;
@@ -1511,6 +1560,14 @@ int swr_texture_set_filter(swr_context* c, swr_texture* t, int bilinear) {
     SWR_ENTER(c);
     if (!t) return fail(c, SWR_ERR_INVALID_ARG, "texture is null");
     t->bilinear = bilinear != 0;          // read when a draw is recorded
+    if (t->bilinear && !t->d_blocked && (t->w & 3) == 0 && (t->h & 3) == 0) {
+        // the four taps of a bilinear fetch: one 64-byte line 9 times out of 16 from a block-linear copy, two lines always from the
+        // row-major original (same stream as the upload and as the raster kernels that will read it)
+        SWR_HIP(c, hipMalloc((void**)&t->d_blocked, (size_t)t->w * t->h * 4));
+        const int blocks = (int)std::min<size_t>(((size_t)t->w * t->h + 255) / 256, 2048 * 8);
+        hipLaunchKernelGGL(k_block_texture, dim3(blocks), dim3(256), 0, c->stream, (const uint32_t*)t->d_rgba, (uint32_t*)t->d_blocked, t->w, t->h);
+        SWR_HIP(c, hipGetLastError());
+    }
     return SWR_OK;
 }
 
@@ -1520,6 +1577,7 @@ int swr_texture_destroy(swr_context* c, swr_texture* t) {
     int rc = flush_locked(c); if (rc) return rc;
     if ((rc = sync_locked(c))) return rc;
     if (t->d_rgba) (void)hipFree(t->d_rgba);
+    if (t->d_blocked) (void)hipFree(t->d_blocked);
     delete t;
     return SWR_OK;
 }

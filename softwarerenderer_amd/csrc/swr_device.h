@@ -404,6 +404,16 @@ __device__ __forceinline__ float4 texture_sample(const uint8_t* __restrict__ tex
 
 // BUILD-DEFINED bilinear filter with wrap (row N4; no reference semantics -- the formula is stated in
 // oracle/swr_oracle.c:oswr_texture_sample_bilinear and reproduced operation for operation)
+// BLOCKED: the texels are stored block-linear -- 4 x 4-texel blocks of 64 B, blocks row-major (swr_texture_set_filter makes that copy
+// for textures whose sides are multiples of 4; k_block_texture) -- so the 2 x 2 taps of a fragment share ONE 64-byte line 9 times out
+// of 16 instead of never (row-major: two rows, one line each, W * 4 bytes apart).  The result is layout-independent by construction:
+// only the address of texel (x, y) changes.
+template <bool BLOCKED>
+__device__ __forceinline__ uint32_t bilinear_texel_offset(int w, int x, int y) {
+    if (BLOCKED) return ((((uint32_t)y >> 2) * ((uint32_t)w >> 2) + ((uint32_t)x >> 2)) << 4) + (((uint32_t)y & 3u) << 2) + ((uint32_t)x & 3u);
+    return (uint32_t)y * (uint32_t)w + (uint32_t)x;
+}
+template <bool BLOCKED>
 __device__ __forceinline__ float4 texture_sample_bilinear(const uint8_t* __restrict__ tex, int w, int h, float tu, float tv) {
     const float x = tu * (float)w - 0.5f, y = tv * (float)h - 0.5f;
     const float x0 = floorf(x), y0 = floorf(y);
@@ -411,10 +421,12 @@ __device__ __forceinline__ float4 texture_sample_bilinear(const uint8_t* __restr
     int ix0 = f2i(x0) % w; if (ix0 < 0) ix0 += w;
     int iy0 = f2i(y0) % h; if (iy0 < 0) iy0 += h;
     const int ix1 = ix0 + 1 == w ? 0 : ix0 + 1, iy1 = iy0 + 1 == h ? 0 : iy0 + 1;
-    const uint32_t p00 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy0 * (size_t)w + (size_t)ix0));
-    const uint32_t p10 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy0 * (size_t)w + (size_t)ix1));
-    const uint32_t p01 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy1 * (size_t)w + (size_t)ix0));
-    const uint32_t p11 = *reinterpret_cast<const uint32_t*>(tex + 4 * ((size_t)iy1 * (size_t)w + (size_t)ix1));
+    // (texel index < 2^30: swr_texture_create refuses larger textures)
+    const uint32_t* __restrict__ t32 = reinterpret_cast<const uint32_t*>(tex);
+    const uint32_t p00 = t32[bilinear_texel_offset<BLOCKED>(w, ix0, iy0)];
+    const uint32_t p10 = t32[bilinear_texel_offset<BLOCKED>(w, ix1, iy0)];
+    const uint32_t p01 = t32[bilinear_texel_offset<BLOCKED>(w, ix0, iy1)];
+    const uint32_t p11 = t32[bilinear_texel_offset<BLOCKED>(w, ix1, iy1)];
     const float inv255 = 1.0f / 255.0f;
     float o[4];
 #pragma unroll
@@ -427,8 +439,10 @@ __device__ __forceinline__ float4 texture_sample_bilinear(const uint8_t* __restr
     }
     return make_float4(o[0], o[1], o[2], o[3]);
 }
-__device__ __forceinline__ float4 texture_fetch(const uint8_t* __restrict__ tex, int w, int h_signed, float tu, float tv) {
-    return h_signed < 0 ? texture_sample_bilinear(tex, w, -h_signed, tu, tv) : texture_sample(tex, w, h_signed, tu, tv);
+// w_signed < 0 (bilinear only): `tex` is the block-linear copy of a texture of width -w_signed
+__device__ __forceinline__ float4 texture_fetch(const uint8_t* __restrict__ tex, int w_signed, int h_signed, float tu, float tv) {
+    if (h_signed >= 0) return texture_sample(tex, w_signed, h_signed, tu, tv);
+    return w_signed < 0 ? texture_sample_bilinear<true>(tex, -w_signed, -h_signed, tu, tv) : texture_sample_bilinear<false>(tex, w_signed, -h_signed, tu, tv);
 }
 
 }  // namespace swr

@@ -280,7 +280,11 @@ __device__ __forceinline__ float4 shade_dust2_fast(const DrawConsts& u, const Tr
     const int tx = f2i(fu * u.tex_wf), ty = f2i(fv * u.tex_hf);
     ok = ok & ((uint32_t)tx < (uint32_t)u.tex_w) & ((uint32_t)ty < (uint32_t)u.tex_h);
     // (an unsafe lane still loads: the index is clamped into the texture, its texel is never used)
+#ifdef SWR_ABL_TEXFIXED      // tools/ablate.py latency probe (wrong image by design): every lane fetches one of 64 neighbouring texels
+    const uint32_t ti = min((uint32_t)ty * (uint32_t)u.tex_w + (uint32_t)tx, (uint32_t)(u.tex_w * u.tex_h - 1)) & 63u;
+#else
     const uint32_t ti = min((uint32_t)ty * (uint32_t)u.tex_w + (uint32_t)tx, (uint32_t)(u.tex_w * u.tex_h - 1));
+#endif
     typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
     const uint32_t texel = ((global_u32_ptr)(uintptr_t)u.tex)[ti];
     __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
@@ -363,6 +367,15 @@ __global__ __launch_bounds__(256) void k_texture_sample(const uint8_t* __restric
                                                         const float2* __restrict__ uv, int n, float4* __restrict__ out) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = texture_sample(tex, w, h, uv[i].x, uv[i].y);
+}
+
+// row-major RGBA8 -> block-linear (4 x 4-texel blocks of 64 B, see bilinear_texel_offset); w and h are multiples of 4
+__global__ __launch_bounds__(256) void k_block_texture(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int w, int h) {
+    const size_t n = (size_t)w * (size_t)h;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) {
+        const int x = (int)(i % (size_t)w), y = (int)(i / (size_t)w);
+        dst[bilinear_texel_offset<true>(w, x, y)] = src[i];
+    }
 }
 
 // sums the per-tile fragment counters; one block (accumulate: adds to out3 instead of overwriting it)

@@ -729,6 +729,47 @@ def test_pipelining_modes_render_the_same_frames():
     ra.close(); rb.close(); dev.close()
 
 
+def test_big_and_small_batches_alternate_between_one_stream_and_frames_in_flight():
+    """Mode 1 (default) pipelines batches of up to 2^17 triangles and runs bigger ones on the context's stream alone; both kinds share
+    the front-end-only buffers, so the hand-over between the two placements is ordered by events in both directions.  An
+    order-dependent sequence small, BIG, small, BIG, small without any synchronisation must give the oracle's frame; so must mode 2."""
+    from oracle.binding import OracleRenderer
+    from softwarerenderer_amd import Device
+    W, H = 640, 480
+    big = scenes.cfg3(W, H, (2, 2), (190, 95), tex_size=64, seed=95)              # 144,400 triangles > 2^17
+    assert big.n_triangles > (1 << 17)
+    small = scenes.state_scene(W, H, 1200, seed=96, blend=BlendMode.Alpha)
+    small2 = scenes.state_scene(W, H, 900, seed=97, blend=BlendMode.Additive)
+    for s_ in (small, small2, big):
+        s_.clear_color = None; s_.clear_depth = False
+    first = scenes.cfg2(W, H, 800, seed=98)                                         # clears
+    seq = [first, big, small, big, small2, big, small]
+    o = OracleRenderer(W, H)
+    for s_ in seq:
+        rc, rd = o.render_scene(s_)
+    o.close()
+    for mode in (1, 2, 0):
+        dev = Device(0)
+        dev.set_pipelining(mode)
+        rs = {}
+        win = None
+        for s_ in (first, big, small, small2):
+            rs[id(s_)] = scenes.SceneRenderer(dev, s_, window=win)
+            win = rs[id(s_)].window
+        for s_ in seq:                                       # sizes the buffers (first round synchronous), then the real thing
+            rs[id(s_)].submit_frame(); dev.flush()
+        dev.sync()
+        syncs = dev.sync_count()
+        for s_ in seq:
+            rs[id(s_)].submit_frame(); dev.flush()
+        assert dev.sync_count() == syncs, mode             # neither placement makes the host wait
+        c, d = win._read()
+        assert_frame_parity(c, d, rc, rd, 1, f"mixed batch sizes, pipelining mode {mode}")
+        for r in rs.values():
+            r.close()
+        dev.close()
+
+
 def test_present_loop_over_array_draws_never_waits_for_the_next_frame():
     """swr_render_mesh_arrays -- the reference's RenderMesh(vertices, indices, ...) -- makes a transient mesh per
     call; swr_present_wait used to hipFree the retired ones, which synchronises the device, i.e. waits for frame i + 1.  Now they are

@@ -240,6 +240,17 @@ def test_bilinear_extension_matches_its_oracle_definition(device):
     assert not np.array_equal(c_near, c_bil)          # the filter really changes the image
 
 
+@pytest.mark.parametrize("tex_size", [64, 36, 30])
+def test_bilinear_texture_layouts_give_the_same_frame(device, tex_size):
+    """The bilinear filter reads a block-linear device copy (4 x 4-texel blocks of 64 B, made by swr_texture_set_filter) when the
+    texture's sides are multiples of 4 (64, 36) and the row-major original otherwise (30): the layout only moves addresses, so both
+    must give the oracle's frame (wrap at the texture's edges included: UVs run over [-2, 3])."""
+    s = scenes.cfg3(320, 240, (2, 2), (20, 14), tex_size=tex_size, seed=83)
+    s.bilinear = True
+    s.name += f"_bilinear_{tex_size}"
+    run_both(device, s)
+
+
 def test_loaded_gltf_model_renders_like_the_oracle(device, tmp_path):
     """Row N4 end to end: glTF -> modelloader.Model -> one RenderDust2-style frame, GPU against the oracle."""
     import json

@@ -10,7 +10,7 @@ from softwarerenderer_amd import _native      # noqa: E402
 _native.LIB_PATH = os.path.join(ROOT, sys.argv[1])
 from softwarerenderer_amd import Device, scenes      # noqa: E402
 
-scene = getattr(scenes, sys.argv[2])()
+scene = scenes.cfg3(bilinear=True) if sys.argv[2] == "cfg3_bilinear" else getattr(scenes, sys.argv[2])()
 dev = Device(0)
 try:
     dev.set_pipelining(0)
