@@ -326,6 +326,94 @@ __device__ __forceinline__ bool dust2_fast_applies(const DrawConsts& u) {
     return u.tex != nullptr && u.tex_h > 0 && u.tex_w > 0 && u.fog_r1 != 0.0f && finite_l;
 }
 
+// ---- the same for the build-defined 4-light program (cfg4): Interpolate + fs_phong4 as one straight-line block -------------------------
+// fs_phong4 guards nine square roots / normalisations per fragment (view vector, and per light: distance, direction, half vector)
+// plus Interpolate's three regions, and reads its 35 uniform words through a generic pointer (vector loads).  Here every core runs
+// unconditionally, the conditions under which each core IS the exact operation are ANDed into `safe` (all operands of a division
+// core or square-root core in [2^-40, 2^40], the interpolated normal's length in range, the texel index inside the texture), the
+// light's `dist / range` becomes the division core on a reciprocal refined once per light, and the uniforms come through the
+// constant address space (scalar loads).  In the verified case every operand is finite, so MathF.Max(0, x) is `x > 0 ? x : 0`
+// (-0 -> +0 like mathf_max) and Math.Clamp is a median.  A chunk with an unsafe lane is shaded again by shade_fragment.
+__device__ __forceinline__ float4 shade_phong4_fast(const DrawParams* __restrict__ dp_generic, const DrawConsts& u, const TriVaryings& V,
+                                                   float w0f, float w1f, float w2f, bool& safe) {
+    typedef const DrawParams __attribute__((address_space(4)))* const_ptr;
+    const const_ptr dp = (const_ptr)(uintptr_t)dp_generic;
+    const float ra = div_core(w0f, V.a_w, V.a_r1), rb = div_core(w1f, V.b_w, V.b_r1), rc = div_core(w2f, V.c_w, V.c_r1);     // :576-578
+    const float inv_sum = (ra + rb) + rc;                                                                                      // :579
+    const float w = recip_core(inv_sum);                                                                                       // :582
+    bool ok = V.fastdiv & div_operands_safe3_arith(w0f, w1f, w2f) & (__builtin_fabsf(inv_sum) >= 0x1p-40f);
+#define SWR_PERSP(a_, b_, c_) ((((a_) * ra + (b_) * rb) + (c_) * rc) * w)
+    const float tu = SWR_PERSP(V.a_uvn.x, V.b_uvn.x, V.c_uvn.x), tv = SWR_PERSP(V.a_uvn.y, V.b_uvn.y, V.c_uvn.y);
+    float fu = tu - (float)f2i(tu), fv = tv - (float)f2i(tv);                                                                  // Texture.cs:43-54
+    fu += (fu < 0) ? 1.0f : 0.0f;
+    fv += (fv < 0) ? 1.0f : 0.0f;
+    const int tx = f2i(fu * u.tex_wf), ty = f2i(fv * u.tex_hf);
+    ok = ok & ((uint32_t)tx < (uint32_t)u.tex_w) & ((uint32_t)ty < (uint32_t)u.tex_h);
+    const uint32_t ti = min((uint32_t)ty * (uint32_t)u.tex_w + (uint32_t)tx, (uint32_t)(u.tex_w * u.tex_h - 1));
+    typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
+    const uint32_t texel = ((global_u32_ptr)(uintptr_t)u.tex)[ti];
+    __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
+    const float cr = SWR_PERSP(V.a_col.x, V.b_col.x, V.c_col.x), cg = SWR_PERSP(V.a_col.y, V.b_col.y, V.c_col.y),
+                cb = SWR_PERSP(V.a_col.z, V.b_col.z, V.c_col.z), ca = SWR_PERSP(V.a_col.w, V.b_col.w, V.c_col.w);
+#undef SWR_PERSP
+    const float wa = ra * w, wb = rb * w, wc = rc * w;                                                                         // :583-585
+    float n0 = (V.a_uvn.z * wa + V.b_uvn.z * wb) + V.c_uvn.z * wc;                                                             // :680-688
+    float n1 = (V.a_uvn.w * wa + V.b_uvn.w * wb) + V.c_uvn.w * wc;
+    float n2 = (V.a_wnz * wa + V.b_wnz * wb) + V.c_wnz * wc;
+    const float len_sq = dot3(n0, n1, n2, n0, n1, n2);
+    ok = ok & (len_sq > 1e-6f) & (len_sq <= 1.0e12f);
+    const float sc = recip_core(sqrt_core(len_sq));
+    n0 = n0 * sc; n1 = n1 * sc; n2 = n2 * sc;
+    float wp[3];                                                                                                               // :690-693
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wp[i] = (V.a_wpos[i] * wa + V.b_wpos[i] * wb) + V.c_wpos[i] * wc;
+    // fs_phong4 (formula: oracle/swr_oracle.c)
+    auto max0 = [](float x) { return x > 0.0f ? x : 0.0f; };
+    auto unit = [&ok](const float v[3], float out[3]) -> float {          // out = v / |v|, returns |v|; collects the cores' conditions
+        const float ll = dot3(v[0], v[1], v[2], v[0], v[1], v[2]);
+        const float len = sqrt_core(ll);
+        const float r1 = rcp_refined(len);
+        out[0] = div_core(v[0], len, r1); out[1] = div_core(v[1], len, r1); out[2] = div_core(v[2], len, r1);
+        // (ll in [2^-40, 2^40] puts len = sqrt(ll) in [2^-20, 2^20]: the division core's range for the denominator needs no test of its own)
+        ok = (bool)((int)ok & (int)div_operand_safe(ll) & (int)div_operands_safe3(v[0], v[1], v[2]));
+        return len;
+    };
+    const float4 tc = texture_unpack(texel);
+    const float base[4] = { cr * tc.x, cg * tc.y, cb * tc.z, ca * tc.w };
+    const float Vd[3] = { dp->u.camera_position[0] - wp[0], dp->u.camera_position[1] - wp[1], dp->u.camera_position[2] - wp[2] };
+    float Vn[3];
+    (void)unit(Vd, Vn);
+    float acc[3] = { 0.1f * base[0], 0.1f * base[1], 0.1f * base[2] };
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const float lpx = dp->u.lights[l].position[0], lpy = dp->u.lights[l].position[1], lpz = dp->u.lights[l].position[2];
+        const float range = dp->u.lights[l].range, inten = dp->u.lights[l].intensity;
+        const float lc[3] = { dp->u.lights[l].color[0], dp->u.lights[l].color[1], dp->u.lights[l].color[2] };
+        const float Ld[3] = { lpx - wp[0], lpy - wp[1], lpz - wp[2] };
+        float Ln[3];
+        const float dist = unit(Ld, Ln);
+        const float ndotl = max0(dot3(n0, n1, n2, Ln[0], Ln[1], Ln[2]));
+        ok = ok & div_operand_safe(range);                                    // (dist: checked by unit())
+        const float q = div_core(dist, range, rcp_refined(range));
+        float att = __builtin_amdgcn_fmed3f(1.0f - q, 0.0f, 1.0f);
+        att = att * att;
+        const float Hd[3] = { Ln[0] + Vn[0], Ln[1] + Vn[1], Ln[2] + Vn[2] };
+        float H[3];
+        (void)unit(Hd, H);
+        float sp = max0(dot3(n0, n1, n2, H[0], H[1], H[2]));
+        sp = sp * sp; sp = sp * sp; sp = sp * sp; sp = sp * sp;
+        const float k = inten * att;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float term = (base[i] * ndotl + sp) * (lc[i] * k);
+            acc[i] = acc[i] + term;
+        }
+    }
+    safe = ok;
+    return make_float4(acc[0], acc[1], acc[2], base[3]);
+}
+__device__ __forceinline__ bool phong4_fast_applies(const DrawConsts& u) { return u.tex != nullptr && u.tex_h > 0 && u.tex_w > 0; }
+
 // SWR_PROG_DEBUG_VARYINGS: Rasterizer.Interpolate for the varyings no other built-in program reads -- Normal (Rasterizer.cs:610-613),
 // ScreenCoords (:390, :598-601), Barycentric (:583-585, :638) -- and the build-defined program that returns them.  Plain IEEE
 // divisions (a debug program: no division cores).  na/nb/nc = the three outputs' Normal, s?x/s?y = their screen positions (TriRec).

@@ -422,7 +422,7 @@ __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
 // 21 up to 7,680 B, 25 up to 6,400 B, 32 up to 5,120 B)
 static_assert(sizeof(WaveLdsC<false>) <= 10240 && sizeof(WaveLdsC<true>) <= 8960, "16 (18) waves per CU need <= 10,240 (8,960) B of LDS per wave");
 template <bool LINES, bool PHONG, int PROG = -1, int BLEND = -1, int DT = -1, bool EARLYOUT = false>
-__global__ __launch_bounds__(64, PHONG ? 5 : 4) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
+__global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 4) void k_raster_c(RasterArgs a, const uint4* __restrict__ masks,
                                                                   const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
     if (batch_poisoned(a.ctrl, a.seq)) return;
@@ -833,6 +833,7 @@ __global__ __launch_bounds__(64, PHONG ? 5 : 4) void k_raster_c(RasterArgs a, co
             if (draw0 != dc_draw) {                                                       // wave-uniform: the constants live in SGPRs across chunks
                 dc_draw = draw0; dc = load_draw_consts(cdp);
                 if (!PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG) fast_draw = dust2_fast_applies(dc);
+                if (PHONG && !LINES && PROG == SWR_PROG_PHONG_4POINT) fast_draw = phong4_fast_applies(dc);
             }
             const int f_program = PROG >= 0 ? PROG : dc.program, f_blend = BLEND >= 0 ? BLEND : dc.blend, f_dt = DT >= 0 ? DT : dc.depth_test;
             // outputs[0].Interpolate: every program but FLAT_COLOR sets it (k_setup), and the clipper's vertices always do
@@ -885,13 +886,14 @@ __global__ __launch_bounds__(64, PHONG ? 5 : 4) void k_raster_c(RasterArgs a, co
                         const float4 src = make_float4(w0f, w1f, w2f, 1.0f);
 #else
                         float4 src = make_float4(0.f, 0.f, 0.f, 0.f);
-                        constexpr bool FAST = !PHONG && !LINES && PROG == SWR_PROG_DUST2_LAMBERT_FOG;
+                        constexpr bool FAST = !LINES && ((!PHONG && PROG == SWR_PROG_DUST2_LAMBERT_FOG) || (PHONG && PROG == SWR_PROG_PHONG_4POINT));
                         const TriVaryings Vs = VG ? load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 2, Vg) : load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u);
                         bool need_exact = !(FAST && fast_draw);           // wave-uniform
                         if (FAST && fast_draw) {
                             // speculate: the straight-line shader; verify: every shaded lane of the chunk took only legal shortcuts
                             bool safe;
-                            src = shade_dust2_fast(dc, Vs, w0f, w1f, w2f, safe);
+                            if constexpr (PHONG) src = shade_phong4_fast(cdp, dc, Vs, w0f, w1f, w2f, safe);
+                            else src = shade_dust2_fast(dc, Vs, w0f, w1f, w2f, safe);
                             need_exact = SWR_BALLOT(!safe) != 0ull;
                         }
                         if (need_exact)

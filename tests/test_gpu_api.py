@@ -730,14 +730,15 @@ def test_pipelining_modes_render_the_same_frames():
 
 
 def test_big_and_small_batches_alternate_between_one_stream_and_frames_in_flight():
-    """Mode 1 (default) pipelines batches of up to 2^17 triangles and runs bigger ones on the context's stream alone; both kinds share
-    the front-end-only buffers, so the hand-over between the two placements is ordered by events in both directions.  An
-    order-dependent sequence small, BIG, small, BIG, small without any synchronisation must give the oracle's frame; so must mode 2."""
+    """Mode 1 (default) pipelines small frames (<= 2^15 tiles) and small batches (<= 2^17 triangles) and runs the rest on the context's
+    stream alone; both kinds share the front-end-only buffers, so the hand-over between the two placements is ordered by events in both
+    directions.  An order-dependent sequence small, BIG, small, BIG, small without any synchronisation on a 3072^2 target (36,864
+    tiles) must give the oracle's frame; so must modes 2 and 0."""
     from oracle.binding import OracleRenderer
     from softwarerenderer_amd import Device
-    W, H = 640, 480
+    W, H = 3072, 3072
     big = scenes.cfg3(W, H, (2, 2), (190, 95), tex_size=64, seed=95)              # 144,400 triangles > 2^17
-    assert big.n_triangles > (1 << 17)
+    assert big.n_triangles > (1 << 17) and (W // 16) * (H // 16) > (1 << 15)
     small = scenes.state_scene(W, H, 1200, seed=96, blend=BlendMode.Alpha)
     small2 = scenes.state_scene(W, H, 900, seed=97, blend=BlendMode.Additive)
     for s_ in (small, small2, big):
