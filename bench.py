@@ -350,8 +350,12 @@ def main():
             isolated = {"raster_ms_median": round(float(np.median(iso)), 4), "raster_ms_min": round(float(iso[0]), 4),
                         "raster_ms_max": round(float(iso[-1]), 4), "launches": int(iso.size),
                         "ms_per_step_unpipelined": round(1e3 * t_iso / n_iso, 4)}
-        dev.profile_reset(); dev.profile_enable(1)
-        n_extra = 5
+        dev.profile_enable(1)
+        for _ in range(3):
+            step()
+        barrier()
+        dev.profile_reset()
+        n_extra = 20
         for _ in range(n_extra):
             step()
         barrier()

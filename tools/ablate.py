@@ -2,8 +2,7 @@
 """Timing-only A/B of kernel variants: for each EXTRA flag set, rebuild the library, run N frames of a config and print
 per-stage hipEvent times.  Outputs of ablated builds are wrong by design; the tracked library is restored afterwards.
 usage: ablate.py cfg3 "" "-DSWR_ABLATE_PHASE2" "lib:build_ab/ref.so" ...
-A variant "env:NAME=VALUE[,..]" times the in-tree library as it is under those environment variables (run-time switches such as
-SWR_RASTER_GRID).  A variant "lib:PATH" times a prebuilt library instead (boxes differ by a few percent: keep a reference library in
+A variant "env:NAME=VALUE[,..]" times the in-tree library as it is under those environment variables.  A variant "lib:PATH" times a prebuilt library instead (boxes differ by a few percent: keep a reference library in
 build_ab/ -- git-ignored, but it travels with gpurun -- and compare inside ONE call)."""
 import os, shutil, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

@@ -7,10 +7,9 @@ lib = os.path.join(ROOT, "softwarerenderer_amd", "libswr_hip.so")
 bak = lib + ".bak"
 shutil.copy(lib, bak)
 try:
-    cover = "--cover" in sys.argv          # k_cover's walk instead: useful pixel steps against executed ones (extra flags may follow)
-    argv = [x for x in sys.argv[1:] if x != "--cover"]
-    extra = " ".join(argv[1:])
-    subprocess.run(["make", "-C", csrc, "-s", "-B", "EXTRA=" + ("-DSWR_DEBUG_COVER " + extra if cover else "-DSWR_DEBUG_COUNTERS")], check=True)
+    argv = sys.argv[1:]
+    # (the variant carries its switches in swr_build_info's `extra=`: left in the product's place it fails the identity test)
+    subprocess.run(["make", "-C", csrc, "-s", "-B", "EXTRA=-DSWR_DEBUG_COUNTERS"], check=True)
     from softwarerenderer_amd import Device, scenes
     cfg = argv[0] if argv else "cfg3"
     scene = getattr(scenes, cfg)()
@@ -22,11 +21,6 @@ try:
     r.render()
     dev._lib.swr_debug_counters(dev._ctx, out)
     st = dev.stats()
-    if cover:
-        useful, executed, waves = int(out[0]), int(out[1]), int(out[2])
-        print(cfg, extra, "k_cover walk: lane steps useful", useful, "executed", executed, "ratio", round(executed / max(useful, 1), 3),
-              "steps per wave", round(executed / 64 / max(waves, 1), 1), "useful per lane", round(useful / 64 / max(waves, 1), 1))
-        raise SystemExit(0)
     names = ["batches", "chunks", "max_col_steps", "max_row_steps", "chunk_lanes", "sum_row_steps", "sum_col_steps", "hiz_hidden_fragments"]
     d = dict(zip(names, [int(v) for v in out]))
     print(cfg, d)
