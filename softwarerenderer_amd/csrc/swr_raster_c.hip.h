@@ -401,6 +401,21 @@ struct __attribute__((aligned(16))) WaveLdsC {
     __device__ __forceinline__ float rt_w(int t) const { return rowtab4[0][VG ? t : 0].w; }
 };
 
+// tools/phase_times.py (-DSWR_DEBUG_PHASES, never the product): shader-clock ticks a wave spends in each phase of k_raster_c, summed
+// over all waves into RasterArgs::dbg.  Every mark is an s_memtime + s_waitcnt lgkmcnt(0), i.e. it also waits for the wave's
+// outstanding LDS operations: the marked kernel runs slower than the product and reads that wait into the phase that ends there.
+//   0 tile init   1 batch: window, hi-Z, selection   2 batch: staging (loads, edge set-up, LDS writes)   3 chunk: lookup (-> pixel)
+//   4 chunk: election + cut   5 chunk: chain replay + depth   6 chunk: shading, blend, next lookup   7 write-back + statistics
+#ifdef SWR_DEBUG_PHASES
+#define SWR_PHASE_DECL unsigned ph_t = (unsigned)__builtin_readcyclecounter(), ph_acc[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
+#define SWR_PHASE(i) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); ph_acc[i] += now_ - ph_t; ph_t = now_; } while (0)
+#define SWR_PHASE_FLUSH(dbg) do { if ((threadIdx.x & 63) == 0 && (dbg)) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(dbg)[i_], (unsigned long long)ph_acc[i_]); } while (0)
+#else
+#define SWR_PHASE_DECL
+#define SWR_PHASE(i) ((void)0)
+#define SWR_PHASE_FLUSH(dbg) ((void)0)
+#endif
+
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
 __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
     int base = 0;
@@ -426,6 +441,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
                                                                   const uint2* __restrict__ info) {
     __shared__ WaveLdsC<PHONG> s_w;
     if (batch_poisoned(a.ctrl, a.seq)) return;
+    SWR_PHASE_DECL
 
     const int lane = threadIdx.x & 63;
     // hi-Z needs every draw of the batch to use Less / LessEqual (stored depth only grows): compile-time state, or the host's word
@@ -572,6 +588,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
     uint32_t dc_draw = 0xffffffffu;
     uint32_t batch_no = 0;
     bool fast_draw = false;                // the chunk's draw satisfies the per-draw conditions of shade_dust2_fast
+    SWR_PHASE(0);
     for (uint32_t base = 0; base < n; ++batch_no) {
         // ---- batch: empty pairs (binning is conservative) and hidden ones are dropped, the first BATCH survivors
         //      of the window are staged in LDS ----
@@ -634,6 +651,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
         }
         const int cincl = cscan;                                             // taken lanes precede every lane that was zeroed: their prefix sums stand
         const int total = consumed > 0 ? __builtin_amdgcn_readlane(cscan, min(consumed, 64) - 1) : 0;
+        SWR_PHASE(1);
         if (total == 0) continue;
         const unsigned long long nzb = SWR_BALLOT(cnt > 0);
         const int ci = __popcll(nzb & ((1ull << lane) - 1ull));              // compacted index of this lane's pair
@@ -734,6 +752,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
             pre_n = __float_as_uint(L.stage[3][t_n].w);
         };
         lookup_ahead(0);
+        SWR_PHASE(2);
         for (int pos = 0; pos < total;) {
             const int g = pos + lane;
             const bool valid = g < total;
@@ -793,6 +812,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
             //  that way (chunks average 57.8 of 64 fragments on cfg3, 60.2 on cfg2); an election by plain byte stores +
             //  read-back, 5 instructions cheaper, lets the HIGHEST lane win and halved cfg2's chunks, and with a second
             //  store round it cost two LDS round trips: cfg3 -1.5 %, cfg2 +6 %.)
+            SWR_PHASE(3);
             const int pix_first = __builtin_amdgcn_readfirstlane(pix);
             // (every predicate is balloted where its compare is: the ballot of ONE compare is the compare's own lane mask, while a
             //  ballot of a combined or branch-carried bool is materialised in a VGPR and compared again)
@@ -819,6 +839,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
                                                (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)win_lo);
                 t0 += __popcll(cut >= 64 ? win : (win & ((1ull << cut) - 1ull)));
             }
+            SWR_PHASE(4);
             const bool act = lane < cut;
             if (VG) { if (act) Vg = load_varyings(t, (dflags & SWR_FLAG_FASTDIV) != 0u, 1); }
             {   // (the head array has two spare words behind the last position: reading past the batch's end is in bounds)
@@ -876,6 +897,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }
             }
+            SWR_PHASE(5);
             lookup_ahead(pos + cut);           // all lanes; its LDS reads return during the shading below
             if (act) {
                 if (!EARLYOUT) {
@@ -967,6 +989,7 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
                 }
             }
             pos += cut;
+            SWR_PHASE(6);
         }
     }
 
@@ -990,6 +1013,8 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
     n_shaded = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_shaded, lane), 63);
     n_written = (unsigned)__builtin_amdgcn_readlane(wave_incl_scan((int)n_written, lane), 63);
     if (lane == 0) a.tile_work[tile] = n_tested;            // the next flush's scheduling weight (k_scan_apply)
+    SWR_PHASE(7);
+    SWR_PHASE_FLUSH(a.dbg);
     if (lane == 0 && n > 0) {
         uint32_t* ts = a.tile_stats + 3u * tile;
         atomicAdd(&ts[0], n_tested); atomicAdd(&ts[1], n_shaded); atomicAdd(&ts[2], n_written);     // no return value: no round trip
