@@ -402,19 +402,40 @@ struct __attribute__((aligned(16))) WaveLdsC {
 };
 
 // tools/phase_times.py (-DSWR_DEBUG_PHASES, never the product): shader-clock ticks a wave spends in each phase of k_raster_c, summed
-// over all waves into RasterArgs::dbg.  Every mark is an s_memtime + s_waitcnt lgkmcnt(0), i.e. it also waits for the wave's
+// over every 64th wave (dispatch index: spread evenly over the heaviest-first order) into RasterArgs::dbg.  Every mark is an s_memtime + s_waitcnt lgkmcnt(0), i.e. it also waits for the wave's
 // outstanding LDS operations: the marked kernel runs slower than the product and reads that wait into the phase that ends there.
 //   0 tile init   1 batch: window, hi-Z, selection   2 batch: staging (loads, edge set-up, LDS writes)   3 chunk: lookup (-> pixel)
 //   4 chunk: election + cut   5 chunk: chain replay + depth   6 chunk: shading, blend, next lookup   7 write-back + statistics
 #ifdef SWR_DEBUG_PHASES
-#define SWR_PHASE_DECL unsigned ph_t = (unsigned)__builtin_readcyclecounter(), ph_acc[8] = { 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
-#define SWR_PHASE(i) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); ph_acc[i] += now_ - ph_t; ph_t = now_; } while (0)
-#define SWR_PHASE_FLUSH(dbg) do { if ((threadIdx.x & 63) == 0 && (dbg)) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&(dbg)[i_], (unsigned long long)ph_acc[i_]); } while (0)
+#define SWR_PHASE_DECL unsigned ph_t = (unsigned)__builtin_readcyclecounter(), ph_acc0 = 0u, ph_acc1 = 0u, ph_acc2 = 0u, ph_acc3 = 0u, \
+                                ph_acc4 = 0u, ph_acc5 = 0u, ph_acc6 = 0u, ph_acc7 = 0u;
+#define SWR_PHASE(i) do { const unsigned now_ = (unsigned)__builtin_readcyclecounter(); ph_acc##i += now_ - ph_t; ph_t = now_; } while (0)
+#define SWR_PHASE_FLUSH(dbg) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63u) == 0u && (dbg)) {   /* every 64th wave: 65,536 waves on 8 addresses are a storm */ \
+        atomicAdd(&(dbg)[0], (unsigned long long)ph_acc0); atomicAdd(&(dbg)[1], (unsigned long long)ph_acc1); \
+        atomicAdd(&(dbg)[2], (unsigned long long)ph_acc2); atomicAdd(&(dbg)[3], (unsigned long long)ph_acc3); \
+        atomicAdd(&(dbg)[4], (unsigned long long)ph_acc4); atomicAdd(&(dbg)[5], (unsigned long long)ph_acc5); \
+        atomicAdd(&(dbg)[6], (unsigned long long)ph_acc6); atomicAdd(&(dbg)[7], (unsigned long long)ph_acc7); } } while (0)
 #else
 #define SWR_PHASE_DECL
 #define SWR_PHASE(i) ((void)0)
 #define SWR_PHASE_FLUSH(dbg) ((void)0)
 #endif
+
+// n steps of the reference's incremental edge chain (Rasterizer.cs:527-534) for this lane, 0 <= n <= MAXN: exactly n float additions per
+// edge, in order.  As a per-lane loop (`for (i < n)`) this was three adds, a compare, two exec updates and a TAKEN branch per
+// iteration, ~10 iterations per chunk: 1,219 of a chunk's 4,229 wave ticks went into the replay (tools/phase_times.py, round 4) --
+// branch latency, not arithmetic.  Here the steps are predicated (a lane that is done just sits out the add) and only every fourth
+// step asks the WAVE whether anybody still has steps left: one forward branch, taken once.
+template <int MAXN>
+__device__ __forceinline__ void replay_chain(float& w0, float& w1, float& w2, int n, float s0, float s1, float s2) {
+#pragma unroll
+    for (int g = 0; g < MAXN; g += 4) {
+        if (SWR_BALLOT(n > g) == 0ull) break;                    // wave-uniform
+#pragma unroll
+        for (int i = g; i < g + 4 && i < MAXN; ++i)
+            if (i < n) { w0 += s0; w1 += s1; w2 += s2; }
+    }
+}
 
 // index (0..31) of the k-th (0-based) set bit of w; requires k < popc(w)
 __device__ __forceinline__ int kth_set_bit32(uint32_t w, int k) {
@@ -890,9 +911,9 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
                         if (EARLYOUT) L.rt_load(qi_e, t, t0r_e, t1r_e, t2r_e);
                         if (q > 0) { w0 = t0r_e; w1 = t1r_e; w2 = t2r_e; }          // (read ahead of the election, see there)
                         const int rem = nrow & (RT_ROWS - 1);
-                        for (int i = 0; i < rem; ++i) { w0 += f3.x; w1 += f3.y; w2 += f3.z; }             // :532-534
+                        replay_chain<RT_ROWS - 1>(w0, w1, w2, rem, f3.x, f3.y, f3.z);                      // :532-534
                     }
-                    for (int i = 0; i < ncol; ++i) { w0 += f2.x; w1 += f2.y; w2 += f2.z; }                // :527-529
+                    replay_chain<15>(w0, w1, w2, ncol, f2.x, f2.y, f2.z);                                  // :527-529
                     w0f = w0 * inv_area; w1f = w1 * inv_area; w2f = w2 * inv_area;                        // :498-500
                     d = (d0 * w0f + d1 * w1f) + d2 * w2f;                                                 // :502
                 }

@@ -830,3 +830,27 @@ def test_a_frame_presented_before_a_later_overflow_is_not_reported_stale():
     assert dev.replay_count() == before + 1
     assert_frame_parity(c, d, rb_, rbd, 1, "late overflow")
     r0.close(); r1.close(); dev.close()
+
+
+def test_a_single_draw_beyond_the_batch_limit_is_refused_when_it_is_recorded():
+    """one batch holds fewer than 2^26 vertex-stage records (vertices + 4 x triangles).  Several draws are flushed in time; a
+    SINGLE mesh beyond the limit used to reach execute_batch and fail there with advice that could not help ("flush more often").  It
+    is refused by swr_render_mesh itself now, with what to do, and the context stays usable."""
+    from softwarerenderer_amd import Device
+    from softwarerenderer_amd._native import SwrError, SWR_ERR_UNSUPPORTED
+    device = Device(0)                                       # its own context: the accepted draw below leaves multi-GB buffers behind
+    n_tris = (1 << 24) + 8                                   # 4 x n_tris alone reaches 2^26
+    v = scenes.make_vertices([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    idx = np.zeros(3 * n_tris, dtype=np.uint16)              # degenerate triangles: only their number matters
+    win = MainWindow(device, 64, 64)
+    prog = scenes.ShaderProgram(scenes.Program.FlatColor, None, None)
+    I = np.eye(4, dtype=np.float32)
+    with pytest.raises(SwrError) as e:
+        Rasterizer.RenderMesh(win, v, idx, I, I, I, prog.VertexShader, prog.FragmentShader)
+    assert e.value.code == SWR_ERR_UNSUPPORTED and "2^26" in str(e.value) and "split" in str(e.value)
+    # one triangle fewer than the limit allows is recorded (and rendered: every triangle is degenerate, nothing is written)
+    ok = np.zeros(3 * ((1 << 24) - 4), dtype=np.uint16)
+    Rasterizer.RenderMesh(win, v, ok, I, I, I, prog.VertexShader, prog.FragmentShader)
+    device.sync()
+    assert device.stats()["triangles_in"] >= (1 << 24) - 4
+    device.close()

@@ -50,7 +50,7 @@ def main():
     build(["-DSWR_DEBUG_COUNTERS"] + extra, cn)
     import json
     child = "import sys, json; sys.path.insert(0, %r); from tools.phase_times import counters; print(json.dumps(counters(sys.argv[1], sys.argv[2], 0)))" % ROOT
-    t = json.loads(subprocess.run([sys.executable, "-c", child, ph, cfg], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    t = [64.0 * v for v in json.loads(subprocess.run([sys.executable, "-c", child, ph, cfg], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])]     # every 64th wave reports
     c = json.loads(subprocess.run([sys.executable, "-c", child, cn, cfg], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
     batches, chunks = c[0], c[1]
     total = sum(t)
