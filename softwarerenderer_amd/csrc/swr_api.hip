@@ -86,7 +86,7 @@ struct RasterSet {
     DevBuf d_vout, d_vnorm, d_recs;
     DevBuf d_masks, d_pcounts, d_pair_refs;
     DevBuf d_tile_count, d_tile_start;
-    DevBuf d_order;          // [tile_work n_tiles][tile_order n_tiles][hist 256][cursor 256] u32, [tile_bucket n_tiles] u8: heaviest-first raster order
+    DevBuf d_order;          // [tile_order n_tiles] uint4 {tile, list start, pairs, -}, [tile_work n_tiles][hist 256][cursor 256] u32, [tile_bucket n_tiles] u8: heaviest-first raster order
     uint32_t hist_tiles = 0; // tile count the fragment history in d_order (tile_work) belongs to (0: none yet)
     hipEvent_t front_done = nullptr, raster_done = nullptr;
     bool raster_pending = false;      // raster_done has been recorded and the stream has not been drained since
@@ -491,9 +491,9 @@ int bin_and_raster(swr_context* c, RasterSet& S, hipStream_t F, const Batch& b, 
     int rc;
     const Ctrl* ctrl = c->d_ctrl.as<Ctrl>();
     unsigned long long* d_total = c->d_total.as<unsigned long long>();
-    uint32_t* tile_work = S.d_order.as<uint32_t>();
-    uint32_t* tile_order = tile_work + n_tiles;
-    uint32_t* order_hist = tile_order + n_tiles;                  // [hist 256][cursor 256]
+    uint4* tile_order = S.d_order.as<uint4>();                    // (16-byte records first: alignment)
+    uint32_t* tile_work = reinterpret_cast<uint32_t*>(tile_order + n_tiles);
+    uint32_t* order_hist = tile_work + n_tiles;                   // [hist 256][cursor 256]
     uint8_t* tile_bucket = reinterpret_cast<uint8_t*>(order_hist + 2 * SWR_ORDER_BUCKETS);     // [n_tiles]
     BinArgs ba = make_bin_args(c, S, b, lo, hi);
     ba.replayable = mode == MODE_ASYNC ? 1u : 0u;
@@ -558,7 +558,7 @@ int bin_and_raster(swr_context* c, RasterSet& S, hipStream_t F, const Batch& b, 
         ScopedSpan sp(c, ST_SORT, F);
         hipLaunchKernelGGL(k_sort_tiles, dim3((n_tiles + SWR_SORT_TPB * SWR_SORT_TPW - 1u) / (SWR_SORT_TPB * SWR_SORT_TPW)), dim3(64 * SWR_SORT_TPB), 0, F, S.d_tile_start.as<uint32_t>(),
                            S.d_tile_count.as<uint32_t>(), c->d_tile_list.as<uint32_t>(), n_tiles, c->d_pair_tile.as<uint32_t>(), ctrl, b.seq,
-                           (const uint32_t*)tile_order);
+                           (const uint4*)tile_order);
         SWR_HIP(c, hipGetLastError());
     }
     if (cover_items) {
@@ -742,7 +742,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     if ((rc = ensure(c, c->d_want, (size_t)(spt * T) + 64))) return rc;
     if ((rc = ensure(c, S.d_tile_count, (size_t)n_tiles * 4))) return rc;
     if ((rc = ensure(c, S.d_tile_start, (size_t)n_tiles * 4))) return rc;
-    if ((rc = ensure(c, S.d_order, (size_t)n_tiles * 9 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
+    if ((rc = ensure(c, S.d_order, (size_t)n_tiles * 25 + 2 * SWR_ORDER_BUCKETS * 4))) return rc;
     if (c->tile_stats_tiles != n_tiles) {
         // another tile count (resize / band change): the fragment counters gathered so far move into the carry words of d_total
         // (swr_get_stats adds them), in stream order, so totals survive a change of geometry
@@ -758,7 +758,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     // the set's buffers were last read by the raster kernel of two flushes ago
     if (piped && S.raster_pending) SWR_HIP(c, hipStreamWaitEvent(F, S.raster_done, 0));
     if (S.hist_tiles != n_tiles) {
-        SWR_HIP(c, hipMemsetAsync(S.d_order.p, 0, (size_t)n_tiles * 4, F));      // no fragment history for this tiling in this set
+        SWR_HIP(c, hipMemsetAsync(S.d_order.as<uint4>() + n_tiles, 0, (size_t)n_tiles * 4, F));      // tile_work: no fragment history for this tiling in this set
         S.hist_tiles = n_tiles;
     }
     char* stage = (char*)slot_acquire(c, up_bytes);
@@ -792,7 +792,7 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
                            d_draws, d_vblocks, S.d_vout.as<VOut>(), d_visible,
                            reinterpret_cast<float*>((char*)S.d_upload.p + offsetof(DrawParams, fog_r1)),
                            dbgv ? S.d_vnorm.as<float4>() : (float4*)nullptr, S.d_tile_count.as<uint32_t>(), n_tiles,
-                           S.d_order.as<uint32_t>() + 2 * (size_t)n_tiles);
+                           reinterpret_cast<uint32_t*>(S.d_order.as<uint4>() + n_tiles) + n_tiles);
         SWR_HIP(c, hipGetLastError());
     }
     const bool counts_clear = !vblocks.empty() && n_tiles != 0;      // k_vertex cleared the per-tile counters and the order histogram

@@ -47,7 +47,7 @@ struct BinArgs {
     const uint8_t* __restrict__ tile_bucket;    // k_scan_apply: order_bucket of every tile
     const uint32_t* __restrict__ order_hist;    // tiles per bucket
     uint32_t* __restrict__ order_cursor;        // per bucket: tiles placed so far
-    uint32_t* __restrict__ tile_order;
+    uint4* __restrict__ tile_order;             // per dispatch position: {tile, first list entry, pairs, -} (tile_place_block)
 };
 
 // Can triangle (sx, sy, pixel bbox) cover ANY pixel of tile (tx, ty)?  Conservative: returns false only when
@@ -175,7 +175,15 @@ __device__ __forceinline__ void tile_place_block(const BinArgs& a, uint32_t bloc
     __syncthreads();
     if (mine) s_cnt[t] = (s_suf[t] - a.order_hist[t]) + atomicAdd(&a.order_cursor[t], mine);
     __syncthreads();
-    if (i != 0xffffffffu) a.tile_order[s_cnt[b] + rank] = i;
+    // The record carries what the tile's sort wave and raster wave would otherwise fetch with two more dependent loads (order -> tile ->
+    // start / count -> list): its list start, and its pair count as the difference of two starts -- the scan is final here, the counts
+    // are not (this block runs in k_bin<FILL>'s grid, whose cursors they are).
+    if (i != 0xffffffffu) {
+        const uint32_t n_tiles = (uint32_t)(a.tiles_x * a.order_tiles_y);
+        const uint32_t st = a.tile_start[i];
+        const unsigned long long nxt = i + 1u < n_tiles ? (unsigned long long)a.tile_start[i + 1u] : *a.total;
+        a.tile_order[s_cnt[b] + rank] = make_uint4(i, st, (uint32_t)(nxt - st), 0u);
+    }
 }
 
 // what binning needs to know about one primitive slot
@@ -608,7 +616,7 @@ __global__ __launch_bounds__(64 * SWR_SORT_TPB) SWR_FRONT_VGPRS void k_sort_tile
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_list, uint32_t n_tiles,
                                                    uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl, uint32_t seq,
-                                                   const uint32_t* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
+                                                   const uint4* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
                                                        pairs sort for 10+ us in one wave and must not start last */) {
     __shared__ uint32_t s_keys_all[SWR_SORT_TPB][SWR_SORT_LDS];
     static_assert(sizeof(s_keys_all) <= SWR_FRONT_MAX_LDS, "k_sort_tiles must fit beside the raster kernel (swr_device.h)");
@@ -617,16 +625,12 @@ __global__ __launch_bounds__(64 * SWR_SORT_TPB) SWR_FRONT_VGPRS void k_sort_tile
     const uint32_t first = (blockIdx.x * SWR_SORT_TPB + (threadIdx.x >> 6)) * SWR_SORT_TPW;
     const uint32_t lane = threadIdx.x & 63u;
     // counts and starts of the wave's tiles in one round trip (lane t: tile first + t)
-#ifdef SWR_SORT_INDEX_ORDER
-    const bool mine = lane < SWR_SORT_TPW && first + lane < n_tiles;
-    const uint32_t tile_l = first + lane;
-#else
     // wave w takes entries w, w + waves, w + 2 waves, ... of the order: its first tile is among the heaviest, its last among the lightest
     const uint32_t waves = gridDim.x * SWR_SORT_TPB, entry = (first / SWR_SORT_TPW) + lane * waves;
     const bool mine = lane < SWR_SORT_TPW && entry < n_tiles;
-    const uint32_t tile_l = mine ? tile_order[entry] : 0u;
-#endif
-    const uint32_t cnt_l = mine ? tile_count[tile_l] : 0u, st_l = mine ? tile_start[tile_l] : 0u;
+    const uint4 desc_l = mine ? tile_order[entry] : make_uint4(0u, 0u, 0u, 0u);      // {tile, start, pairs}: one load instead of three dependent ones
+    const uint32_t tile_l = desc_l.x;
+    const uint32_t cnt_l = desc_l.z, st_l = desc_l.y;
     uint32_t keys[SWR_SORT_TPW];           // entry `lane` of every tile's segment: all in flight before the first sort
 #pragma unroll
     for (int t = 0; t < SWR_SORT_TPW; ++t) {

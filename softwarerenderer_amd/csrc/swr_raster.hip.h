@@ -20,7 +20,7 @@ struct RasterArgs {
     const float4* __restrict__ vnorm;          // VertexOutput.Normal per VOut entry (DEBUG_VARYINGS batches only, else null)
     uint32_t vout_bytes;                       // size of the VOut array (< 4 GiB: k_raster_c addresses it with 32-bit byte offsets)
     const uint4* __restrict__ pair_refs;       // per pair {slot, vertex refs of outputs[0..2]} (k_cover)
-    const uint32_t* __restrict__ tile_order;   // band-local tile indices, heaviest first (tile_place_block)
+    const uint4* __restrict__ tile_order;      // per dispatch position, heaviest first: {band-local tile, first list entry, pairs, -} (tile_place_block)
     uint32_t* __restrict__ tile_work;          // out: fragments tested per tile in this flush = the next flush's scheduling weight
     uint32_t n_tiles;
     float4* __restrict__ color;

@@ -470,23 +470,24 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
     // Workgroups go round-robin to the 8 XCDs, in index order as slots free up.  The order array is cut in segments of
     // 64 entries (neighbouring tiles of similar weight, see order_tile_of_thread); XCD x works through segments x, x+8, ...:
     // still heaviest-first chip-wide (granularity 512 tiles), and a segment's shared triangle data stays in one L2.
-    uint32_t tile_o;
+    uint4 desc;                            // {tile, first list entry, pairs}: ONE scalar load, then the window fetch (round 3: three dependent loads)
     {
         const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
         const uint32_t j = (((k >> 6) << 3) + xcd) * 64u + (k & 63u);
         if (j >= a.n_tiles) return;
-        tile_o = a.tile_order[j];
+        desc = a.tile_order[j];
     }
+    const uint32_t tile_o = desc.x;
     const int tx = (int)(tile_o % (uint32_t)a.fp.tiles_x), ty_local = (int)(tile_o / (uint32_t)a.fp.tiles_x);
     if (tx >= a.fp.tiles_x || ty_local >= a.fp.band_tile_rows) return;
     const int ty = band_global_row(band_map(a.fp), ty_local);
     const uint32_t tile = (uint32_t)(ty_local * a.fp.tiles_x + tx);
-    const uint32_t n = a.tile_count[tile];
+    const uint32_t n = desc.z;              // (= tile_count[tile] after FILL: the difference of two list starts)
     if (n == 0 && !a.clear_color_on && !a.clear_depth_on) {
         if (threadIdx.x == 0) a.tile_work[tile] = 0u;
         return;
     }
-    const uint32_t start = a.tile_start[tile];
+    const uint32_t start = desc.y;
     WaveLdsC<PHONG>& L = s_w;
     constexpr bool VG = WaveLdsC<PHONG>::VG;
     constexpr int RT_ROWS = WaveLdsC<PHONG>::RT_ROWS;
