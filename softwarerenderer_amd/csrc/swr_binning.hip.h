@@ -69,9 +69,6 @@ struct BinArgs {
 __device__ __forceinline__ bool pair_may_cover(const float sx[3], const float sy[3], int minX, int maxX, int minY, int maxY,
                                                int tx, int ty, int width, int height, bool is_line) {
     if (is_line) return true;         // DrawLine edges: keep every tile of the line's bbox (the test below is for triangles)
-#ifdef SWR_ABL_NOPMC                  // tools/ablate.py timing experiments only
-    return true;
-#endif
     const int x0 = tx * SWR_TILE, y0 = ty * SWR_TILE;
     const int startX = max(minX, x0), endX = min(maxX, min(x0 + SWR_TILE - 1, width - 1));
     const int startY = max(minY, y0), endY = min(maxY, min(y0 + SWR_TILE - 1, height - 1));
@@ -131,11 +128,7 @@ __device__ __forceinline__ uint32_t order_bucket(uint32_t w) {
     const uint32_t m = e >= 3 ? ((w >> (e - 3)) & 7u) : ((w << (3 - e)) & 7u);
     return min((uint32_t)(e * 8) + m + 1u, (uint32_t)SWR_ORDER_BUCKETS - 1u);
 }
-#ifdef SWR_ORDER_BY_PAIRS          // A/B: no fragment history
-__device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return 16u * pairs; }
-#else
 __device__ __forceinline__ uint32_t tile_weight(uint32_t frags, uint32_t pairs) { return frags + 16u * pairs; }
-#endif
 
 // Thread i of an ordering block -> tile: a block takes a 16x16-tile region, a wave an 8x8 quarter of it, so that
 // tiles which end up next to each other in the order (same block, same bucket, consecutive LDS ranks) are neighbours
@@ -313,9 +306,7 @@ __device__ __forceinline__ void bin_big(const BinArgs& a, const SlotData& sd, ui
 // keyed by tile -- neighbouring triangles share tiles, so 256 triangles touch few distinct ones -- and only one
 // global atomic per distinct tile leaves the block; FILL gets each pair's rank from the LDS add and the tile's base
 // from that one global atomic.  The order inside a tile's list is irrelevant here (k_sort_tiles restores it).
-#ifndef SWR_BIN_TABLE_LOG2
 #define SWR_BIN_TABLE_LOG2 8
-#endif
 #define SWR_BIN_TABLE (1 << SWR_BIN_TABLE_LOG2)     // a block rarely touches more than a few hundred distinct tiles; probing is bounded and
                                                   // a pair that finds no slot goes to the global counter directly
 // one slot per thread of a 256-thread block (tb = its tile bbox word, SWR_TB_INVALID: nothing); every thread of the block must call
@@ -527,12 +518,8 @@ __device__ __forceinline__ void cmpx_glb(uint32_t* g, uint32_t i, uint32_t p, ui
 // One wave sorts one tile at a time, SWR_SORT_TPW tiles one after the other, SWR_SORT_TPB waves per block (they never meet: no block
 // barrier).  A tile's sort is ~850 cycles of one wave, and 65,536 waves that short are bound by the rate at which waves can be
 // launched (about one per clock chip-wide: 3.5 waves resident per CU on average, 26 us); fewer, longer waves are not.
-#ifndef SWR_SORT_TPB
 #define SWR_SORT_TPB 1                 // (round 3: 4 -- 32 KB of LDS per block; one wave and 8 KB fit beside the raster kernel, swr_device.h)
-#endif
-#ifndef SWR_SORT_TPW
 #define SWR_SORT_TPW 4
-#endif
 // what a one-wave workgroup's __syncthreads() amounts to: the wave's own LDS / global accesses complete in order
 #define SWR_SORT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 // key_in: entry `lane` of the segment when n <= 64 (the kernel fetches the first 64 entries of all its tiles in one round trip)
@@ -541,9 +528,7 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
     if (n == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     // band-local tile index of every pair of this segment (k_cover reads it): contiguous, coalesced
-#ifndef SWR_ABL_SORT_NOPT
     for (uint32_t i = lane; i < n; i += 64) pair_tile[start + i] = tile;
-#endif
     if (n < 2) return;
     uint32_t* seg = tile_list + start;
 
@@ -561,14 +546,12 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
                     SWR_CMPX((lane & 4u) ? up : dn, (lane & 4u) == 0u) }
 #define SWR_XOR8  SWR_CMPX(SWR_DPP(0x128), (lane & 8u) == 0u)                        /* row_ror:8 */
 #define SWR_XOR16 SWR_CMPX(__shfl((int)key, (int)(lane ^ 16u)), (lane & 16u) == 0u)
-#ifndef SWR_ABL_SORT_NONET          // tools/ablate.py timing experiments only (wrong order by design)
         SWR_XOR1                                                                      // k = 2 (its flip is xor 1)
         SWR_CMPX(SWR_DPP(0x1B), (lane & 2u) == 0u) SWR_XOR1                           // k = 4: flip = quad_perm [3,2,1,0]
         SWR_CMPX(SWR_DPP(0x141), (lane & 4u) == 0u) SWR_XOR2 SWR_XOR1                 // k = 8: flip = row_half_mirror
         SWR_CMPX(SWR_DPP(0x140), (lane & 8u) == 0u) SWR_XOR4 SWR_XOR2 SWR_XOR1        // k = 16: flip = row_mirror
         SWR_CMPX(__shfl((int)key, (int)(lane ^ 31u)), (lane & 16u) == 0u) SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1              // k = 32
         SWR_CMPX(__shfl((int)key, (int)(lane ^ 63u)), (lane & 32u) == 0u) SWR_XOR16 SWR_XOR8 SWR_XOR4 SWR_XOR2 SWR_XOR1    // k = 64
-#endif
 #undef SWR_XOR16
 #undef SWR_XOR8
 #undef SWR_XOR4
@@ -580,9 +563,6 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
         return;
     }
 
-#ifdef SWR_ABL_SORT_NOBIG
-    return;
-#endif
     uint32_t m = 1;
     while (m < n) m <<= 1;
     const bool in_lds = n <= SWR_SORT_LDS;

@@ -35,7 +35,6 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
     if (visible && !visible[bm.draw]) return;          // RenderMesh was not called for this mesh (frustum culled)
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;
-#ifndef SWR_VERTEX_DIRECT_STORES
     // A lane's 64-byte record leaves as four 16-byte stores, 64 bytes apart from its neighbour's: 256 partial line writes per wave.
     // The wave's 64 records go through LDS instead and leave as four stores of 1 KB each (consecutive lanes, consecutive 16 bytes).
     // (and the other way round for the 48-byte input vertices: three loads of 1 KB each per wave, handed out through LDS)
@@ -46,7 +45,6 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
     const uint32_t wv_ = threadIdx.x >> 6, lane_ = threadIdx.x & 63u;
     const uint32_t first_ = bm.first + wv_ * 64u;                // first vertex of the wave
     const uint32_t n_live_ = dp->n_verts > first_ ? min(dp->n_verts - first_, 64u) : 0u;
-#ifndef SWR_VERTEX_DIRECT_LOADS
     {
         const float4* __restrict__ src = reinterpret_cast<const float4*>(dp->verts + first_);
         float4* sw = &s_out[wv_][0];
@@ -58,27 +56,14 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-#endif
     if (live) {
-#else
-    if (local >= dp->n_verts) return;
-    {
-#endif
     if (local == 0u) {      // once per draw: the refined reciprocal of the fog range (see div_core in swr_device.h)
         const float den = dp->u.fog_end - dp->u.fog_start;
         fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float))] = div_operand_safe(den) ? rcp_refined(den) : 0.0f;
         fog_r1_of_draw0[(size_t)bm.draw * (sizeof(DrawParams) / sizeof(float)) + 3] = den;      // DrawParams::fog_den
     }
 
-#if !defined(SWR_VERTEX_DIRECT_STORES) && !defined(SWR_VERTEX_DIRECT_LOADS)
     const float4 q0 = s_out[wv_][3 * lane_], q1 = s_out[wv_][3 * lane_ + 1], q2 = s_out[wv_][3 * lane_ + 2];   // pos.xyz uv.x | uv.y normal.xyz | color
-#else
-    const float* __restrict__ vin = reinterpret_cast<const float*>(dp->verts + local);
-    // 48-byte vertex = three 16-byte loads
-    const float4 q0 = *reinterpret_cast<const float4*>(vin);       // pos.xyz, uv.x
-    const float4 q1 = *reinterpret_cast<const float4*>(vin + 4);   // uv.y, normal.xyz
-    const float4 q2 = *reinterpret_cast<const float4*>(vin + 8);   // color
-#endif
 
     float p[4] = { q0.x, q0.y, q0.z, 1.0f };
     float world[4], viewp[4], clip[4];
@@ -90,21 +75,12 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
     vec3_transform_normal(n, dp->model, tn, fma_tn);   // :835
     float len = sqrtf(dot3(tn[0], tn[1], tn[2], tn[0], tn[1], tn[2]));   // Vector3.Normalize = v / Length()
 
-#ifdef SWR_VERTEX_DIRECT_STORES
-    float4* o = reinterpret_cast<float4*>(vout + dp->vert_base + local);
-    o[0] = make_float4(clip[0], clip[1], clip[2], clip[3]);
-    o[1] = q2;
-    o[2] = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
-    o[3] = make_float4(tn[2] / len, world[0], world[1], world[2]);
-#else
     o0 = make_float4(clip[0], clip[1], clip[2], clip[3]);
     o1 = q2;
     o2 = make_float4(q0.w, q1.x, tn[0] / len, tn[1] / len);
     o3 = make_float4(tn[2] / len, world[0], world[1], world[2]);
-#endif
     if (vnorm) vnorm[dp->vert_base + local] = make_float4(n[0], n[1], n[2], 0.0f);      // Normal = input.Normal, Renderer.cs:842
     }
-#ifndef SWR_VERTEX_DIRECT_STORES
     {
         const uint32_t wv = wv_, lane = lane_;
         float4* sw = &s_out[wv][0];                       // the wave's 64 records: record l = entries 4 l .. 4 l + 3
@@ -121,7 +97,6 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
             if ((e >> 2) < n_live) dst[e] = sw[e];
         }
     }
-#endif
 }
 
 // a vertex moving through clip + setup: the stored varyings plus the Interpolate flag
@@ -228,9 +203,6 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
     if (minX > maxX || minY > maxY) return 0;                                            // :442
 
     float4* out = rec_regs ? rec_regs : reinterpret_cast<float4*>(rec);
-#ifdef SWR_ABL_SETUP_NOSTORE           // tools/ablate.py timing experiments only
-    if (inv_area == 12345.678f)
-#endif
     {
     out[0] = make_float4(sx[0], sx[1], sx[2], sy[0]);
     out[1] = make_float4(sy[1], sy[2], dz[0], dz[1]);
@@ -249,11 +221,7 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 // One thread per submitted triangle.  Filled mode: slot 2*t is the triangle itself (or the first fan triangle of
 // its clipped polygon), slot 2*t+1 the second fan triangle.  Wireframe: six slots per triangle, three DrawLine
 // edges per fan triangle, in the reference's call order.  Slots keep submission order, which the per-tile lists preserve.
-#ifdef SWR_NO_FRAG_ALIAS            // tools/ablate.py A/B: every draw keeps its own index (a chunk is cut at every mesh boundary)
-#define SWR_FRAG_DRAW(dp, bm) ((bm).draw)
-#else
 #define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
-#endif
 __global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves per SIMD = 64 VGPRs: beside the raster kernel, swr_device.h)
         const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
@@ -354,12 +322,10 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves p
                                                           pbase, pbase + 2, pbase + 3, recs + slot + per_fan, &tbs[3], wireframe != 0);
                 }
             } else {
-#ifndef SWR_SETUP_DIRECT_STORES
                 if (!wireframe) {
                     rec_valid = setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], false, rec_q) != 0;
                     n_setup += rec_valid ? 1u : 0u;
                 } else
-#endif
                 n_setup += setup_triangle(fp, dp->cull, SWR_FRAG_DRAW(dp, bm), v[0], v[1], v[2], r0, r1, r2, recs + slot, &tbs[0], wireframe != 0);
             }
         }
@@ -371,7 +337,6 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves p
         }
     }
 
-#ifndef SWR_SETUP_DIRECT_STORES
     // A lane's 64-byte TriRec would leave as four 16-byte stores, 128 bytes apart from its neighbour's (256 partial line writes per
     // wave: 16 of the kernel's 37 us).  The wave's records go through LDS and leave as four stores of sixteen whole records each.
     {
@@ -393,7 +358,6 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves p
             }
         }
     }
-#endif
     // block-level counter reduction, then one atomic per counter per block into a replica
     __shared__ unsigned s_cnt[3];
     if (threadIdx.x < 3) s_cnt[threadIdx.x] = 0;

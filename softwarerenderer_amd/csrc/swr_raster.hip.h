@@ -85,12 +85,8 @@ __device__ __forceinline__ float4 fs_dust2(const DrawConsts& u, const Frag& f) {
     fog = (fog * fog) * (3.0f - 2.0f * fog);
     float s = 0.1f + 0.9f * diffuse;
     float4 tc = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-#ifndef SWR_ABL_NOTEX          // tools/ablate.py timing experiments only (wrong image by design)
     if (f.texel_loaded) tc = texture_unpack(f.texel);
     else if (u.tex) tc = texture_fetch(u.tex, u.tex_w, u.tex_h, f.u, f.v);
-#else
-    tc.x = f.u; tc.y = f.v;
-#endif
     float4 base = make_float4(f.color.x * tc.x, f.color.y * tc.y, f.color.z * tc.z, f.color.w * tc.w);
     float4 o;
     o.x = nm_lerp(u.fog_color[0], (base.x * s) * u.light_color[0], fog);
@@ -203,7 +199,6 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
     // The texel fetch is a dependent gather with a long latency: issue it as soon as u,v exist; the rest of the
     // interpolation, the normal and the fog term run while it is in flight.  (Bilinear textures fetch in the program.)
     f.texel = 0u; f.texel_loaded = false;
-#ifndef SWR_ABL_NOTEX
     if (dc.tex && dc.tex_h > 0) {
         // global (not generic) address space + 32-bit index: one global_load with the draw's texture pointer as scalar base
         typedef const uint32_t __attribute__((address_space(1)))* global_u32_ptr;
@@ -215,7 +210,6 @@ __device__ __forceinline__ float4 shade_fragment(const DrawParams* __restrict__ 
         f.texel_loaded = true;
     }
     __builtin_amdgcn_sched_barrier(0);      // keep the load above everything that does not feed its address
-#endif
     if (interp) {
         f.color = make_float4(SWR_PERSP(a_col.x, b_col.x, c_col.x), SWR_PERSP(a_col.y, b_col.y, c_col.y),
                               SWR_PERSP(a_col.z, b_col.z, c_col.z), SWR_PERSP(a_col.w, b_col.w, c_col.w));
