@@ -1,4 +1,5 @@
 """Host-side logic: enum ordinals, scene generators, matrix factories, band partition, bench.py's rank launcher."""
+import importlib.util
 import os
 import sys
 
@@ -119,3 +120,22 @@ def test_bench_does_not_launch_when_it_is_a_rank_or_single_gpu(monkeypatch):
     assert bench.launch_ranks_if_needed(argparse.Namespace(gpus=2, fake_world=2), [], run=boom) is None
     monkeypatch.setenv("WORLD_SIZE", "2")
     assert bench.launch_ranks_if_needed(argparse.Namespace(gpus=2, fake_world=0), [], run=boom) is None
+
+
+def test_multi_gpu_model_predicts_from_the_committed_single_gpu_stage_times():
+    """the N > 1 JSON carries what DESIGN.md section 6 predicts for that N (vertex + setup replicated, the rest divided by
+    N, one 64 GB/s xGMI link per band into rank 0), so that a SCALE run can be read against it line by line."""
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    m1 = bench.multi_gpu_model("cfg3", 1, 4096, 4096, 3)
+    assert m1["gather_ms"] == 0.0
+    prev = None
+    for n in (2, 4, 8):
+        m = bench.multi_gpu_model("cfg3", n, 4096, 4096, 3)
+        assert abs(m["gather_ms"] - 4096 * 4096 * 12 / n / 64e9 * 1e3) < 1e-3          # 201 MB / N over one link
+        assert m["source"] and m["source"].startswith("r") and m["render_ms"] > 0       # a committed profiles/r*_final_bench_with_cpu.json of cfg3
+        assert m["step_ms"] == max(m["render_ms"], m["gather_ms"])
+        assert m["front_ms"] > m["raster_ms"] * 0 and (prev is None or m["render_ms"] < prev)   # rendering scales, the replicated front end does not
+        prev = m["render_ms"]
+    assert bench.multi_gpu_model("cfg2", 2, 1080, 1920, 3)["render_ms"] is None          # no committed single-GPU line of that config: gather only
