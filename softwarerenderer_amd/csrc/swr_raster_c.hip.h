@@ -654,18 +654,15 @@ __global__ __launch_bounds__(64, (PHONG && PROG != SWR_PROG_PHONG_4POINT) ? 5 : 
 #ifdef SWR_DEBUG_COUNTERS
         dbg_hidden += (unsigned)(cnt_seen - cnt);
 #endif
-        // slide the window: what was not consumed moves down, the freed lanes fetch the next entries of the list
+        // slide the window: every lane fetches its entry of the NEXT window (24 B per candidate, consecutive lanes consecutive addresses,
+        // lines this wave touched a batch ago: L2 / L1 hits that return while this batch is rasterised).  Round 3 moved the unconsumed
+        // entries down with six ds_bpermute and fetched only the freed lanes: six LDS-crossbar round trips on the batch's critical path
+        // to save loads nobody waits for.
         base += (uint32_t)consumed;
         {
-            const int src = lane + consumed;
-            uint4 r2;
-            r2.x = (uint32_t)__shfl((int)ref_w.x, src); r2.y = (uint32_t)__shfl((int)ref_w.y, src);
-            r2.z = (uint32_t)__shfl((int)ref_w.z, src); r2.w = (uint32_t)__shfl((int)ref_w.w, src);
-            const int c2 = __shfl(cnt_w, src);
-            const float z2 = __int_as_float(__shfl(__float_as_int(zb_w), src));
-            ref_w = r2; cnt_w = c2; zb_w = z2;
             const uint32_t e = base + (uint32_t)lane;
-            if (lane >= WINDOW - consumed && lane < WINDOW && e < n) {
+            ref_w = make_uint4(0u, 0u, 0u, 0u); cnt_w = 0; zb_w = 0.0f;
+            if (lane < WINDOW && e < n) {
                 ref_w = a.pair_refs[start + e];
                 const uint2 pi = info[start + e];
                 cnt_w = (int)pi.x; zb_w = __uint_as_float(pi.y);
