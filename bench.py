@@ -98,6 +98,8 @@ def main():
         args.gpus = world
     if args.force_dist and (world != 1 or args.fake_world > 1):
         raise SystemExit("--force-dist is the one-rank rehearsal of the N>1 path: use it with --gpus 1 and without --fake-world")
+    if args.force_dist and args.gather == "p2p":
+        raise SystemExit("--force-dist rehearses the RCCL gather modes (a process cannot open its own IPC handle): use rgb32f or rgba32f")
     dist_on = world > 1 or args.force_dist          # the multi-GPU code path (bands, band buffers, gather, checkpoints)
 
     import torch                      # plumbing: device memory for the bands, streams, RCCL
@@ -439,6 +441,8 @@ def main():
                 "kernel_launches_timed": int(samples.size),      # every launch of a timed region of <= 32 steps, else every 4th
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                 "stage_ms_per_step": stage_ms,
+                "stage_note": "20 frames on one stream with an event pair around EVERY stage: a breakdown, not a timing -- back-to-back event records "
+                              "before a kernel lengthen it (raster: +5-8 % against kernel_ms_isolated, which has the pair on that kernel alone)",
             }
             if isolated is not None:
                 iso_ms = isolated["raster_ms_median"]

@@ -350,17 +350,20 @@ void destroy_mesh(swr_mesh* m) {
 // complete goes to the pool, not to hipFree: freeing synchronises the whole device, which is exactly what an asynchronous present
 // loop must not do, and the next call with arrays of that size needs the same buffers again.
 const size_t kMeshPoolBytes = (size_t)1 << 30;
-void pool_mesh(swr_context* c, swr_mesh* m) {
-    c->mesh_pool.push_back(m);
-    c->mesh_pool_bytes += m->cap_verts + m->cap_idx;
-}
-void trim_mesh_pool(swr_context* c) {      // streams must be idle (hipFree): keep the newest meshes up to the byte budget
+void trim_mesh_pool(swr_context* c) {      // keeps the newest meshes up to the byte budget (hipFree: a device-wide wait unless the streams are idle)
     while (c->mesh_pool_bytes > kMeshPoolBytes && !c->mesh_pool.empty()) {
         swr_mesh* m = c->mesh_pool.front();
         c->mesh_pool.erase(c->mesh_pool.begin());
         c->mesh_pool_bytes -= m->cap_verts + m->cap_idx;
         destroy_mesh(m);
     }
+}
+void pool_mesh(swr_context* c, swr_mesh* m) {
+    c->mesh_pool.push_back(m);
+    c->mesh_pool_bytes += m->cap_verts + m->cap_idx;
+    // a present loop that never drains and whose array sizes never repeat would grow the pool for ever: past twice the budget the
+    // oldest (unused: pooled meshes are complete) are freed here, at the price of one device-wide wait
+    if (c->mesh_pool_bytes > 2 * kMeshPoolBytes) trim_mesh_pool(c);
 }
 void free_garbage(swr_context* c) {       // streams must be idle: nothing in flight reads the garbage any more
     for (swr_mesh* m : c->garbage) pool_mesh(c, m);
@@ -392,7 +395,8 @@ int sync_locked(swr_context* c) {
 }
 
 // the stream mesh uploads and front-end-only work go to: the front stream while frames are pipelined, else the context's stream
-hipStream_t front_stream_of(swr_context* c) {
+// (and notes that the front stream now carries work the raster stream has not been ordered behind)
+hipStream_t use_front_stream(swr_context* c) {
     if (c->pipelining && c->front_stream) { c->f_tail_pending = true; return c->front_stream; }
     return c->stream;
 }
@@ -909,7 +913,7 @@ int ensure_bounds(swr_context* c, swr_mesh* m) {
     if (m->bounds_ready) return SWR_OK;
     if (!m->d_bounds) SWR_HIP(c, hipMalloc((void**)&m->d_bounds, sizeof(float4)));
     // (on the stream the mesh was uploaded on and k_frustum_cull will read the result on)
-    hipLaunchKernelGGL(k_bounding_sphere, dim3(1), dim3(1024), 0, front_stream_of(c), (const swr_vertex*)m->d_verts, (uint32_t)m->n_verts, m->d_bounds);
+    hipLaunchKernelGGL(k_bounding_sphere, dim3(1), dim3(1024), 0, use_front_stream(c), (const swr_vertex*)m->d_verts, (uint32_t)m->n_verts, m->d_bounds);
     SWR_HIP(c, hipGetLastError());
     m->bounds_ready = true;
     return SWR_OK;
@@ -1058,8 +1062,8 @@ int make_mesh(swr_context* c, const swr_vertex* v, int nv, const uint16_t* idx, 
         if (e == hipSuccess) m->cap_idx = (size_t)ni * 2 + 8;
     }
     // (only front-end kernels read a mesh: the upload goes to their stream, so a pipelined frame does not wait for the raster stream)
-    if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, front_stream_of(c));
-    if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, front_stream_of(c));
+    if (e == hipSuccess && nv) e = hipMemcpyAsync(m->d_verts, v, (size_t)nv * sizeof(swr_vertex), hipMemcpyHostToDevice, use_front_stream(c));
+    if (e == hipSuccess && ni) e = hipMemcpyAsync(m->d_idx, idx, (size_t)ni * 2, hipMemcpyHostToDevice, use_front_stream(c));
     if (e != hipSuccess) {
         destroy_mesh(m);
         c->err = std::string("mesh upload failed: ") + hipGetErrorString(e);
@@ -1649,8 +1653,8 @@ int swr_mesh_bounds(swr_context* c, const swr_mesh* mesh, float center_radius[4]
     if (!mesh || !center_radius) return fail(c, SWR_ERR_INVALID_ARG, "bad mesh_bounds arguments");
     int rc = ensure_bounds(c, const_cast<swr_mesh*>(mesh));
     if (rc) return rc;
-    SWR_HIP(c, hipMemcpyAsync(center_radius, mesh->d_bounds, 16, hipMemcpyDeviceToHost, front_stream_of(c)));
-    SWR_HIP(c, hipStreamSynchronize(front_stream_of(c)));
+    SWR_HIP(c, hipMemcpyAsync(center_radius, mesh->d_bounds, 16, hipMemcpyDeviceToHost, use_front_stream(c)));
+    SWR_HIP(c, hipStreamSynchronize(use_front_stream(c)));
     return SWR_OK;
 }
 

@@ -170,9 +170,16 @@ __global__ __launch_bounds__(SWR_COVER_BLOCK) SWR_FRONT_VGPRS void k_cover(Cover
         rank = atomicAdd(&s_hist[bucket], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int b = NB - 1; b >= 0; --b) { const uint32_t c = s_hist[b]; s_hist[b] = acc; acc += c; }   // longest first
+    // bucket bases, longest first: base[b] = pairs in the buckets above b.  One wave, one DPP scan over the 64 non-empty-walk buckets
+    // taken in descending order (lane l holds bucket NB - 1 - l), bucket 0 (nothing to walk) behind them all.  (Round 3: thread 0
+    // walked the 65 buckets one LDS round trip after the other while 255 threads waited at the barrier.)
+    static_assert(NB == 65, "one lane per bucket 1..64");
+    if (threadIdx.x < 64) {
+        const uint32_t b = (uint32_t)(NB - 1) - threadIdx.x;                  // 64 .. 1
+        const uint32_t cnt_b = s_hist[b];
+        const uint32_t incl = (uint32_t)wave_incl_scan((int)cnt_b, (int)threadIdx.x);
+        s_hist[b] = incl - cnt_b;
+        if (threadIdx.x == 63) s_hist[0] = incl;                             // every walking pair precedes the empty ones
     }
     __syncthreads();
     s_perm[s_hist[bucket] + rank] = (uint16_t)threadIdx.x;
