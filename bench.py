@@ -71,9 +71,9 @@ def main():
                     help="torch.distributed backend; gloo (control plane only, needs --gather p2p) rehearses the N>1 path with "
                          "several ranks on ONE GPU (SWR_BENCH_ONE_DEVICE=1), which RCCL refuses")
     ap.add_argument("--pipelining", type=int, choices=[0, 1, 2], default=1,
-                    help="frames in flight inside the library (swr_set_pipelining): 1 (the library's default) = frames of up to 2^15 tiles or batches "
-                         "of up to 2^17 triangles run their front end on a second stream beside the previous frame's raster kernel (cfg2: yes; "
-                         "cfg3 / cfg4 / cfg5: no -- measured zero-sum there), 0 = never, 2 = every batch")
+                    help="frames in flight inside the library (swr_set_pipelining): 1 (the library's default) = every frame's front end runs on a "
+                         "second stream beside the previous frame's raster kernel, 0 = never (one stream), 2 = only frames of up to 2^15 tiles or "
+                         "batches of up to 2^17 triangles")
     ap.add_argument("--camera-jitter", type=float, default=0.0,
                     help="perturb the view matrix of every frame on the host (a translation of this amplitude in view space plus a small "
                          "yaw, a different one each frame): the tile order feeds on the previous frame's fragment counts, this shows it is "
@@ -309,6 +309,12 @@ def main():
         dev.sync()
         n_prime += 1
     barrier()
+    # ... and with frames in flight the runtime grows the pools of the SECOND stream (and of the cross-stream events) only once the
+    # queues run deep, i.e. when frames follow each other without a synchronisation: one untimed back-to-back burst does that here
+    # (without it the first ~25 pipelined frames of a process contain a one-off stall of several milliseconds)
+    for _ in range(max(args.prime, 1) if args.pipelining else 0):
+        step()
+    barrier()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -419,10 +425,14 @@ def main():
                                 "forced_one_rank_rehearsal": bool(args.force_dist),
                                 "model": multi_gpu_model(args.config, world, H, W, chan)}
         if prof is not None and prof["raster_launches"] > 0 and samples is not None and samples.size:
-            # dominant kernel = k_raster_c; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1).  Its duration is the
-            # MEDIAN of the per-launch hipEvent samples of the timed region, i.e. with frames in flight when pipelining is on: the
-            # kernel then shares the chip with the next frame's front end, so the one-stream figure rides along (kernel_ms_isolated)
-            raster_ms = float(np.median(samples))
+            # dominant kernel = k_raster_c; algorithmic bytes = 20 B per WRITTEN fragment (rank 0's band at N>1).  With frames in flight
+            # the kernel shares the chip with the NEXT frame's front end during the timed region, and a roofline is a statement about a
+            # kernel that has the chip: `kernel_ms` / `achieved` / `frac` are therefore the median of the per-launch hipEvent samples of
+            # the one-stream pass that follows the timed region in this same process (same frames, same launch count; rocprofv3's
+            # "alone" launches, profiles/*_summary.md), and the timed region's own samples ride along as `timed_region` (rocprofv3's
+            # "beside a front end" launches).  Without pipelining the two are the same measurement twice and must agree within 3 %.
+            timed_ms = float(np.median(samples))
+            raster_ms = isolated["raster_ms_median"] if isolated is not None else timed_ms
             written_local = st["fragments_written"] / args.steps
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
             frame_bytes = (W * H if not dist_on else color_t[0].shape[0] * W) * 20.0
@@ -436,26 +446,34 @@ def main():
                 "traffic_unit": "GB per launch = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes of this build (null: none for this build); algorithmic = written fragments x 20 B",
                 "algorithmic_gb_per_launch": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / 1e9, 4),
                 "kernel_ms": round(raster_ms, 4),
-                "kernel_ms_median": round(raster_ms, 4), "kernel_ms_min": round(float(samples[0]), 4), "kernel_ms_max": round(float(samples[-1]), 4),
-                "kernel_ms_mean": round(prof["raster_ms"] / prof["raster_launches"], 4),
-                "kernel_launches_timed": int(samples.size),      # every launch of a timed region of <= 32 steps, else every 4th
+                "kernel_ms_source": ("one-stream pass behind the timed region (pipelining off: the kernel alone on the chip), hipEvent pair on every launch, median"
+                                     if isolated is not None else "timed region, hipEvent pairs, median"),
                 "frame_level_frac": round(frame_bytes / (raster_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "kernel_launches_timed": int(samples.size),          # launches of the timed region that carried an event pair (all, up to 32 steps)
+                "timed_region": {
+                    "kernel_ms_median": round(timed_ms, 4), "kernel_ms_min": round(float(samples[0]), 4), "kernel_ms_max": round(float(samples[-1]), 4),
+                    "kernel_ms_mean": round(prof["raster_ms"] / prof["raster_launches"], 4),
+                    "kernel_launches_timed": int(samples.size),      # every launch of a timed region of <= 32 steps, else every 4th
+                    "frac": round(written_local * BYTES_PER_WRITTEN_FRAGMENT / (timed_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "note": ("frames in flight: the kernel runs beside the next frame's front end (longer launch, shorter frame)" if args.pipelining
+                             else "one stream: the same measurement as kernel_ms"),
+                },
                 "stage_ms_per_step": stage_ms,
                 "stage_note": "20 frames on one stream with an event pair around EVERY stage: a breakdown, not a timing -- back-to-back event records "
-                              "before a kernel lengthen it (raster: +5-8 % against kernel_ms_isolated, which has the pair on that kernel alone)",
+                              "before a kernel lengthen it (raster: +5-8 % against kernel_ms, which has the pair on that kernel alone)",
             }
             if isolated is not None:
-                iso_ms = isolated["raster_ms_median"]
-                out["roofline"]["kernel_ms_isolated"] = iso_ms
-                out["roofline"]["raster_ms_isolated"] = iso_ms
-                out["roofline"]["frac_isolated"] = round(written_local * BYTES_PER_WRITTEN_FRAGMENT / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-                out["roofline"]["isolated"] = isolated
-                rel = abs(raster_ms - iso_ms) / iso_ms
+                out["roofline"]["kernel_ms_isolated"] = raster_ms            # (= kernel_ms; kept under the name round 3's verdict asked for)
+                out["roofline"]["kernel_ms_median"] = raster_ms
+                out["roofline"]["kernel_ms_min"] = isolated["raster_ms_min"]
+                out["roofline"]["kernel_ms_max"] = isolated["raster_ms_max"]
+                out["roofline"]["kernel_launches"] = isolated["launches"]
+                rel = abs(timed_ms - raster_ms) / raster_ms
                 if rel > 0.03:
-                    out["roofline"]["warning"] = (f"timed-region kernel_ms and the one-stream kernel_ms_isolated differ by {100 * rel:.1f} %"
+                    out["roofline"]["warning"] = (f"the timed region's kernel samples and the one-stream kernel_ms differ by {100 * rel:.1f} %"
                                                   + (": expected with frames in flight (the kernel shares the chip with the next frame's front end)"
                                                      if args.pipelining else ": measurement noise above 3 %"))
-            vf = valu_floor(args.config, world, isolated["raster_ms_median"] if isolated else raster_ms, written_local)
+            vf = valu_floor(args.config, world, raster_ms, written_local)
             if vf is not None:
                 out["roofline"]["valu_floor"] = vf
         if isolated is not None:

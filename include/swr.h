@@ -258,9 +258,9 @@ int  swr_sync(swr_context* ctx);     /* flush + wait for the stream */
  * 163-230: RenderMesh per mesh).  A pipelined flush runs its front end -- vertex stage, clip, setup, binning, coverage -- on a second
  * stream beside the raster kernel of the flush before it (double-buffered intermediates, event-ordered hand-over); pixels, counters
  * and every ordering guarantee against the context's stream are unchanged.  mode: 0 = never (one stream: what kernel timings are
- * quoted on), 1 = frames of up to 2^15 tiles (2896^2 pixels) or batches of up to 2^17 triangles (default: the overlap lives in the
- * raster kernel's tail and in the launch gaps of short front-end kernels -- 1920x1080: -8 ... -16 %; at 4096^2 with 1 M triangles it
- * is +-1 % in steady state and a burst pays one un-overlapped front end to fill the pipe), 2 = every batch.  Switching drains. */
+ * quoted on), 1 = every batch (default: 4096^2 / 1 M triangles -6 %, 1920x1080 -8 ... -16 % in steady state; a burst of K frames from
+ * an idle context pays one un-overlapped front end, +0.2 ms / K), 2 = only frames of up to 2^15 tiles (2896^2 pixels) or batches of
+ * up to 2^17 triangles (bigger ones run on the context's stream, ordered against pipelined neighbours by events).  Switching drains. */
 int  swr_set_pipelining(swr_context* ctx, int mode);
 int  swr_get_pipelining(swr_context* ctx, int* mode);
 

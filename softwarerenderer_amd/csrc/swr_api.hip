@@ -118,8 +118,8 @@ struct swr_context {
     std::string err;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t front_stream = nullptr;    // front ends of pipelined flushes (and mesh uploads, which only front-end kernels read)
-    int pipelining = 1;                    // swr_set_pipelining: 0 off, 1 auto (see execute_batch), 2 every batch
-    uint32_t pipeline_max_tris = 1u << 17; // mode 1: a batch is pipelined when it has at most this many triangles ...
+    int pipelining = 1;                    // swr_set_pipelining: 0 off, 1 every batch (default), 2 small frames / small batches only (see execute_batch)
+    uint32_t pipeline_max_tris = 1u << 17; // mode 2: a batch is pipelined when it has at most this many triangles ...
     uint32_t pipeline_max_tiles = 1u << 15;   // ... or the band at most this many tiles (8 raster waves per wave slot of the chip)
     hipEvent_t f_tail_ev = nullptr, r_front_ev = nullptr;
     bool f_tail_pending = false;           // the front stream carries work (a front end, a mesh upload) the raster stream has not been ordered behind
@@ -670,16 +670,17 @@ int execute_batch(swr_context* c, const Batch& b, int mode, int count_stats) {
     // pipelined flushes alternate between the two RasterSets and run their front end on the front stream; a synchronous batch (the
     // first frame, a replay, SWR_SYNC_FLUSH) reads the pair total back half way and runs on the context's stream alone
     if ((rc = ensure_front_stream(c))) return rc;
-    // Which batches gain (profiles/r04_frames_in_flight.md).  A raster kernel holds every byte of LDS while it has tiles left to start,
-    // so a front-end block runs beside it only in the slot of a retiring raster wave, and what it takes there it takes from the raster
-    // kernel (measured zero-sum); the overlap that pays is in the raster kernel's TAIL and in the launch gaps and ramps of the short
-    // front-end kernels.  1920x1080 (8,160 tiles = two waves of tiles per wave slot): -8 ... -16 % from 32 k to 260 k triangles, still
-    // -5 % at 1 M; 4096x4096 / 1 M triangles (65,536 tiles: the tail is a sixteenth of the kernel): +-1 % in steady state, and a burst
-    // of N frames pays one un-overlapped front end to fill the pipe (+0.45 ms / N).  Mode 1 pipelines small frames OR small batches.
+    // What it buys (profiles/r04_frames_in_flight.md).  A raster kernel holds every byte of LDS while it has tiles left to start, so a
+    // front-end block runs beside it only in the slot of a retiring raster wave and only if it fits what four raster waves per SIMD
+    // leave (SWR_FRONT_MAX_LDS / SWR_FRONT_MAX_VGPRS, swr_device.h).  With every front-end kernel inside that budget the whole front
+    // end of a 4096^2 / 1 M-triangle frame runs beside the previous frame's raster kernel, which pays for the company (392 -> 491 us)
+    // less than the front end costs alone: cfg3 -5.9 %, cfg4 -3.9 %, cfg5 -5.6 % in steady state, 1920x1080 -8 ... -16 %.  A burst of K
+    // frames pays one un-overlapped front end to fill the pipe (+0.2 ms / K); mode 2 keeps big frames on one stream for callers whose
+    // bursts are that short (frames of at most 2^15 tiles or batches of at most 2^17 triangles are pipelined regardless).
     uint64_t n_tris_batch = 0;
     for (auto& d : b.draws) n_tris_batch += d.p.n_tris;
     const uint64_t n_tiles_band = (uint64_t)c->tiles_x * (uint64_t)c->band_tile_rows;
-    const bool piped = mode == MODE_ASYNC && (c->pipelining == 2 || (c->pipelining == 1 && (n_tris_batch <= c->pipeline_max_tris ||
+    const bool piped = mode == MODE_ASYNC && (c->pipelining == 1 || (c->pipelining == 2 && (n_tris_batch <= c->pipeline_max_tris ||
                                                                                             n_tiles_band <= c->pipeline_max_tiles)));
     RasterSet& S = c->sets[c->pipelining ? (b.seq & 1u) : 0u];
     const hipStream_t F = piped ? c->front_stream : c->stream;
@@ -1301,7 +1302,7 @@ int swr_flush(swr_context* c) { SWR_ENTER(c); return flush_locked(c); }
 
 int swr_set_pipelining(swr_context* c, int mode) {
     SWR_ENTER(c);
-    if (mode < 0 || mode > 2) return fail(c, SWR_ERR_INVALID_ARG, "pipelining mode must be 0 (off), 1 (frames of up to 2^15 tiles or batches of up to 2^17 triangles) or 2 (every batch)");
+    if (mode < 0 || mode > 2) return fail(c, SWR_ERR_INVALID_ARG, "pipelining mode must be 0 (off), 1 (every batch) or 2 (only frames of up to 2^15 tiles or batches of up to 2^17 triangles)");
     if (mode == c->pipelining) return SWR_OK;
     int rc = flush_locked(c);
     if (rc) return rc;

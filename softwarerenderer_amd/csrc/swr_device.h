@@ -41,12 +41,17 @@
 #define SWR_TB_INVALID 0xffffffffffffffffull     // slot_tb word of a slot with nothing to rasterise
 
 // Co-residency budget of the FRONT-END kernels (frames in flight, swr_api.hip).  The raster kernel of the previous flush fills every
-// CU with 16 one-wave workgroups of 10,240 B of LDS each (all 160 KB) at ~106 VGPRs (4 waves per SIMD: 64 of 512 registers left
-// per SIMD lane).  A front-end workgroup is placed when one raster wave retires -- so it runs BESIDE the raster kernel only if it
-// fits what that leaves: at most 10,240 B of LDS, 64 VGPRs per wave, 4 waves.  Measured (gpurun_out/r4_pipe*_kernel_trace.csv):
-// k_vertex with 16 KB of LDS per block sat out the whole raster kernel (385-408 us), without LDS it ran beside it in 40 us.
+// CU with 16 one-wave workgroups of 10,240 B of LDS each (all 160 KB) at <= 104 allocated VGPRs (k_raster_c<DUST2>: 103; 4 waves per
+// SIMD: 96 of 512 registers left per SIMD lane).  A front-end workgroup is placed when one raster wave retires -- so it runs BESIDE
+// the raster kernel only if it fits what that leaves: at most 10,240 B of LDS, 96 VGPRs per wave, 4 waves.  Measured
+// (profiles/r04_frames_in_flight.md): k_vertex with 16 KB of LDS per block sat out the whole raster kernel (385-408 us), without LDS
+// it ran beside it in 40 us; with the raster kernel at 106 registers (112 allocated: 64 left) k_bin (69 / 79) waited for its tail
+// and, capped at 64, spilled (+29 us alone) -- three registers fewer in the raster kernel are what let the whole front end in.
+// tests/test_resource_budget.py holds every kernel to this budget (a register more in the wrong place costs the overlap, silently).
 #define SWR_FRONT_MAX_LDS 10240
-#define SWR_FRONT_VGPRS __attribute__((amdgpu_num_vgpr(64)))      // on every front-end kernel, next to its __launch_bounds__
+#define SWR_FRONT_MAX_VGPRS 96
+#define SWR_RASTER_MAX_VGPRS 104
+#define SWR_FRONT_VGPRS __attribute__((amdgpu_num_vgpr(SWR_FRONT_MAX_VGPRS)))      // on the front-end kernels, next to their __launch_bounds__
 #define SWR_GEOM_BLOCK 128                       // threads per k_vertex / k_setup block (vertices / triangles of ONE draw per block)
 
 namespace swr {

@@ -222,8 +222,7 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 // its clipped polygon), slot 2*t+1 the second fan triangle.  Wireframe: six slots per triangle, three DrawLine
 // edges per fan triangle, in the reference's call order.  Slots keep submission order, which the per-tile lists preserve.
 #define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
-__global__ __launch_bounds__(SWR_GEOM_BLOCK, 8) void k_setup(      // (8 waves per SIMD = 64 VGPRs: beside the raster kernel, swr_device.h)
-        const DrawParams* __restrict__ draws,
+__global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_setup(const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
                                                VOut* __restrict__ clip_pool,     // 4 VOut per triangle, indexed by global triangle

@@ -730,10 +730,10 @@ def test_pipelining_modes_render_the_same_frames():
 
 
 def test_big_and_small_batches_alternate_between_one_stream_and_frames_in_flight():
-    """Mode 1 (default) pipelines small frames (<= 2^15 tiles) and small batches (<= 2^17 triangles) and runs the rest on the context's
-    stream alone; both kinds share the front-end-only buffers, so the hand-over between the two placements is ordered by events in both
+    """Mode 2 pipelines small frames (<= 2^15 tiles) and small batches (<= 2^17 triangles) and runs the rest on the context's stream
+    alone; both kinds share the front-end-only buffers, so the hand-over between the two placements is ordered by events in both
     directions.  An order-dependent sequence small, BIG, small, BIG, small without any synchronisation on a 3072^2 target (36,864
-    tiles) must give the oracle's frame; so must modes 2 and 0."""
+    tiles) must give the oracle's frame; so must mode 1 (default: every batch pipelined) and mode 0 (none)."""
     from oracle.binding import OracleRenderer
     from softwarerenderer_amd import Device
     W, H = 3072, 3072

@@ -9,6 +9,6 @@ for cfg in cfg3 cfg2; do for j in 0 0.05; do
 import json
 j=json.loads([l for l in open("gpurun_out/r4_jit_${cfg}_$j.json") if l.startswith("{")][-1])
 r=j["roofline"]
-print("$cfg jitter $j: ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "value", j["value"], "frags", j["fragments_tested_per_frame"], "kernel med", r["kernel_ms_median"], "iso", r.get("kernel_ms_isolated"), "frac", r["frac"], r.get("frac_isolated"))
+print("$cfg jitter $j: ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "value", j["value"], "frags", j["fragments_tested_per_frame"], "kernel med", r["timed_region"]["kernel_ms_median"], "iso", r.get("kernel_ms_isolated"), "frac", r["frac"], r["timed_region"]["frac"])
 PY
 done; done

@@ -8,7 +8,7 @@ for st in 20 50; do
   python - <<PY
 import json
 j=json.loads([l for l in open("gpurun_out/r4_bc.json") if l.startswith("{")][-1])
-print("bench steps $st p=$p events: ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel", j["roofline"]["kernel_ms_median"])
+print("bench steps $st p=$p events: ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel", j["roofline"]["timed_region"]["kernel_ms_median"])
 PY
   timeout -k 10 200 python bench.py --steps $st --warmup 5 --no-cpu-baseline --no-profile-events --pipelining $p > gpurun_out/r4_bc.json 2>/dev/null || exit 1
   python - <<PY

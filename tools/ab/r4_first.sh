@@ -11,7 +11,7 @@ for p in 1 0 2 1 0; do
 import json
 j=json.loads([l for l in open("gpurun_out/r4_b_cfg3_p$p.json") if l.startswith("{")][-1])
 r=j["roofline"]
-print("cfg3 p=$p ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel med/min/max", r["kernel_ms_median"], r["kernel_ms_min"], r["kernel_ms_max"], "iso", r.get("kernel_ms_isolated"), "stages", r["stage_ms_per_step"])
+print("cfg3 p=$p ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel med/min/max", r["timed_region"]["kernel_ms_median"], r["timed_region"]["kernel_ms_min"], r["timed_region"]["kernel_ms_max"], "iso", r.get("kernel_ms_isolated"), "stages", r["stage_ms_per_step"])
 PY
 done
 for p in 1 0; do
@@ -20,6 +20,6 @@ for p in 1 0; do
 import json
 j=json.loads([l for l in open("gpurun_out/r4_b_cfg2_p$p.json") if l.startswith("{")][-1])
 r=j["roofline"]
-print("cfg2 p=$p ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel med", r["kernel_ms_median"], "iso", r.get("kernel_ms_isolated"))
+print("cfg2 p=$p ms/step", j["ms_per_step"], "unpiped", j.get("ms_per_step_unpipelined"), "kernel med", r["timed_region"]["kernel_ms_median"], "iso", r.get("kernel_ms_isolated"))
 PY
 done

@@ -51,6 +51,31 @@ def main():
         lines.append(f"| `{name}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
                      f"{'' if f is None else f'{f * 1024 / 1e6:.1f} ({2 * f * 1024 / 1e6:.1f})'} | "
                      f"{'' if w is None else f'{w * 1024 / 1e6:.1f}'} |")
+    # Frames in flight: a raster launch either shares the chip with the next frame's front end (the pipelined bursts of the command:
+    # warm-up, timed region) or has it to itself (bench.py's one-stream passes behind the timed region, and the synced setup frames).
+    # The aggregate above mixes the two; split by whether any front-end kernel's interval intersects the launch's.
+    kt = glob.glob(os.path.join(stats_dir, "**", "*_kernel_trace.csv"), recursive=True)
+    if kt:
+        tr = [(r["Kernel_Name"].split("(")[0], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kt[0]))]
+        front = sorted((s0, e0) for n, s0, e0 in tr if "swr::" in n and "k_raster_c" not in n and "k_reduce" not in n and "k_clear" not in n
+                       and "k_flatten" not in n)
+        import bisect
+        starts = [f[0] for f in front]
+        beside, alone = [], []
+        for n, s0, e0 in tr:
+            if "k_raster_c" not in n:
+                continue
+            i = bisect.bisect_left(starts, e0)
+            hit = any(front[k][1] > s0 and front[k][0] < e0 for k in range(max(0, i - 12), i))
+            (beside if hit else alone).append((e0 - s0) / 1e3)
+        if beside or alone:
+            med = lambda v: sorted(v)[len(v) // 2] if v else float("nan")
+            lines += ["", "`k_raster_c` launches of this command, split by the kernel trace (does a front-end kernel of the NEXT frame run during "
+                      "the launch?): "
+                      f"**beside a front end** {len(beside)} launches, average {sum(beside) / max(len(beside), 1):.1f} us, median {med(beside):.1f} "
+                      "(= `roofline.timed_region`, frames in flight); "
+                      f"**alone** {len(alone)} launches, average {sum(alone) / max(len(alone), 1):.1f} us, median {med(alone):.1f} "
+                      "(= `roofline.kernel_ms`, the kernel with the chip to itself: bench.py's one-stream pass behind the timed region)."]
     if bench and os.path.exists(bench):
         txt = open(bench).read().strip().splitlines()
         js = [l for l in txt if l.startswith("{")]
