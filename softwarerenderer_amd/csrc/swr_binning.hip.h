@@ -385,6 +385,7 @@ __device__ __forceinline__ void bin_block_slots(const BinArgs& a, uint32_t slot,
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_bin(BinArgs a) {
+    SWR_FRONT_ENTER();
     __shared__ uint32_t s_key[SWR_BIN_TABLE];      // tile + 1; 0 = empty
     __shared__ uint32_t s_val[SWR_BIN_TABLE];      // pairs of this block in the tile; FILL: then their first list position
     if (FILL && batch_poisoned(a.ctrl, a.seq)) return;
@@ -433,6 +434,7 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
 
 __global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
                                                     unsigned long long* __restrict__ sums) {
+    SWR_FRONT_ENTER();
     __shared__ unsigned long long s_part[SWR_SCAN_BLOCK / 64];
     const uint32_t i = blockIdx.x * (uint32_t)SWR_SCAN_BLOCK + threadIdx.x;
     const unsigned long long t = block_sum(i < n ? count[i] : 0u, s_part);
@@ -446,6 +448,7 @@ __global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_apply(u
                                                      Counters* __restrict__ counters, int poison_on_overflow,
                                                      const uint32_t* __restrict__ tile_work, uint32_t* __restrict__ order_hist,
                                                      uint8_t* __restrict__ tile_bucket) {
+    SWR_FRONT_ENTER();
     __shared__ unsigned long long s_part[SWR_SCAN_BLOCK / 64];
     __shared__ unsigned long long s_wave[SWR_SCAN_BLOCK / 64];
     __shared__ uint32_t s_oh[SWR_ORDER_BUCKETS];
@@ -598,6 +601,7 @@ __global__ __launch_bounds__(64 * SWR_SORT_TPB) SWR_FRONT_VGPRS void k_sort_tile
                                                    uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl, uint32_t seq,
                                                    const uint4* __restrict__ tile_order /* heaviest first: the few tiles with hundreds of
                                                        pairs sort for 10+ us in one wave and must not start last */) {
+    SWR_FRONT_ENTER();
     __shared__ uint32_t s_keys_all[SWR_SORT_TPB][SWR_SORT_LDS];
     static_assert(sizeof(s_keys_all) <= SWR_FRONT_MAX_LDS, "k_sort_tiles must fit beside the raster kernel (swr_device.h)");
     if (batch_poisoned(ctrl, seq)) return;

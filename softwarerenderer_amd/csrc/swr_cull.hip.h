@@ -129,6 +129,7 @@ __device__ __forceinline__ bool sphere_in_frustum(float4 sphere, const float* __
 // one thread per draw of the batch: 1 = render, 0 = skipped by the frustum test (draws without a cull request are 1)
 __global__ __launch_bounds__(64) void k_frustum_cull(const DrawParams* __restrict__ draws, const float4* const* __restrict__ bounds,
                                                      uint32_t n_draws, uint32_t* __restrict__ visible) {
+    SWR_FRONT_ENTER();
     const uint32_t d = blockIdx.x * 64u + threadIdx.x;
     if (d >= n_draws) return;
     const float4* b = bounds[d];

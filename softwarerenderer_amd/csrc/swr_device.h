@@ -52,6 +52,11 @@
 #define SWR_FRONT_MAX_VGPRS 96
 #define SWR_RASTER_MAX_VGPRS 104
 #define SWR_FRONT_VGPRS __attribute__((amdgpu_num_vgpr(SWR_FRONT_MAX_VGPRS)))      // on the front-end kernels, next to their __launch_bounds__
+// ... and its waves issue ahead of the raster kernel's on the SIMDs they share (s_setprio 3, first statement of every front-end kernel):
+// with frames in flight the front end of frame N+1, stretched across the raster kernel of frame N, is the critical path (cfg3: 547 us
+// against 492), and on small frames it is starved outright.  Same-box A/B (tools/ab/r4_prio.sh): cfg2 0.138 -> 0.120 ms (-13 %), cfg3
+// 0.563 -> 0.558, cfg5 +-0; priority 1 and 3 measure alike.  Alone on the chip the instruction changes nothing.
+#define SWR_FRONT_ENTER() __builtin_amdgcn_s_setprio(3)
 #define SWR_GEOM_BLOCK 128                       // threads per k_vertex / k_setup block (vertices / triangles of ONE draw per block)
 
 namespace swr {

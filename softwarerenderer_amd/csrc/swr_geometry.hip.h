@@ -28,6 +28,7 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const
                                                 uint32_t* __restrict__ zero_words, uint32_t n_zero /* binning's per-tile counters: cleared
                                                                               here, not by a launch of their own */,
                                                 uint32_t* __restrict__ zero_hist /* and the tile order's histogram + cursors */) {
+    SWR_FRONT_ENTER();
     for (uint32_t i = blockIdx.x * (uint32_t)SWR_GEOM_BLOCK + threadIdx.x; i < n_zero; i += gridDim.x * (uint32_t)SWR_GEOM_BLOCK) zero_words[i] = 0u;
     if (blockIdx.x == 0) for (uint32_t i = threadIdx.x; i < 512u; i += (uint32_t)SWR_GEOM_BLOCK) zero_hist[i] = 0u;
     // (2 x SWR_ORDER_BUCKETS = 512 words, swr_binning.hip.h)
@@ -234,6 +235,7 @@ __global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_setup(const 
                                                const Ctrl* __restrict__ ctrl, uint32_t seq, int count_stats, int wireframe,
                                                const uint32_t* __restrict__ visible,
                                                float4* __restrict__ vnorm /* see k_vertex; the clipper's vertices get theirs here */) {
+    SWR_FRONT_ENTER();
     const BlockMap bm = blocks[blockIdx.x];
     const DrawParams* __restrict__ dp = draws + bm.draw;
     const uint32_t local = bm.first + threadIdx.x;

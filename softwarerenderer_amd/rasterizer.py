@@ -204,7 +204,7 @@ class Device:
 
     def set_pipelining(self, mode: int):
         """swr_set_pipelining: 0 = one stream (kernel timings are quoted on this), 1 = the front end of flush N+1 beside the raster
-        kernel of flush N (default), 2 = the same with the front stream at default priority."""
+        kernel of flush N, every asynchronous batch (default), 2 = the same for small frames / batches only (<= 2^15 tiles or <= 2^17 triangles)."""
         self._ck(self._lib.swr_set_pipelining(self._ctx, int(mode)))
 
     def pipelining(self) -> int:
