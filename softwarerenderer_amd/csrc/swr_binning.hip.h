@@ -432,7 +432,7 @@ __device__ __forceinline__ unsigned long long block_sum(unsigned long long v, un
     return t;
 }
 
-__global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
+__global__ __launch_bounds__(SWR_SCAN_BLOCK) void k_scan_sums(const uint32_t* __restrict__ count, uint32_t n,
                                                     unsigned long long* __restrict__ sums) {
     SWR_FRONT_ENTER();
     __shared__ unsigned long long s_part[SWR_SCAN_BLOCK / 64];
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_sums(co
     if (threadIdx.x == 0) sums[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(SWR_SCAN_BLOCK) SWR_FRONT_VGPRS void k_scan_apply(uint32_t* __restrict__ count, uint32_t* __restrict__ start,
+__global__ __launch_bounds__(SWR_SCAN_BLOCK) void k_scan_apply(uint32_t* __restrict__ count, uint32_t* __restrict__ start,
                                                      uint32_t n, const unsigned long long* __restrict__ sums,
                                                      unsigned long long* __restrict__ total_out,
                                                      unsigned long long capacity, uint32_t seq, Ctrl* __restrict__ ctrl,
@@ -595,7 +595,7 @@ __device__ __forceinline__ void sort_tile(uint32_t n, uint32_t start, uint32_t* 
     }
 }
 
-__global__ __launch_bounds__(64 * SWR_SORT_TPB) SWR_FRONT_VGPRS void k_sort_tiles(const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(64 * SWR_SORT_TPB) void k_sort_tiles(const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_list, uint32_t n_tiles,
                                                    uint32_t* __restrict__ pair_tile, const Ctrl* __restrict__ ctrl, uint32_t seq,

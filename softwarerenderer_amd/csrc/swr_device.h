@@ -47,11 +47,11 @@
 // (profiles/r04_frames_in_flight.md): k_vertex with 16 KB of LDS per block sat out the whole raster kernel (385-408 us), without LDS
 // it ran beside it in 40 us; with the raster kernel at 106 registers (112 allocated: 64 left) k_bin (69 / 79) waited for its tail
 // and, capped at 64, spilled (+29 us alone) -- three registers fewer in the raster kernel are what let the whole front end in.
-// tests/test_resource_budget.py holds every kernel to this budget (a register more in the wrong place costs the overlap, silently).
+// tests/test_resource_budget.py holds every kernel to this budget from the compiler's resource remarks (a register more in the wrong
+// place costs the overlap, silently; this hipcc ignores amdgpu_num_vgpr, so the budget cannot be declared on the kernels themselves).
 #define SWR_FRONT_MAX_LDS 10240
 #define SWR_FRONT_MAX_VGPRS 96
 #define SWR_RASTER_MAX_VGPRS 104
-#define SWR_FRONT_VGPRS __attribute__((amdgpu_num_vgpr(SWR_FRONT_MAX_VGPRS)))      // on the front-end kernels, next to their __launch_bounds__
 // ... and its waves issue ahead of the raster kernel's on the SIMDs they share (s_setprio 3, first statement of every front-end kernel):
 // with frames in flight the front end of frame N+1, stretched across the raster kernel of frame N, is the critical path (cfg3: 547 us
 // against 492), and on small frames it is starved outright.  Same-box A/B (tools/ab/r4_prio.sh): cfg2 0.138 -> 0.120 ms (-13 %), cfg3

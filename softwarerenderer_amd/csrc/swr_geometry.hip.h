@@ -19,7 +19,7 @@ namespace swr {
 // so the draw's matrices are wave-uniform (scalar loads)
 struct BlockMap { uint32_t draw; uint32_t first; };
 
-__global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_vertex(const DrawParams* __restrict__ draws,
+__global__ __launch_bounds__(SWR_GEOM_BLOCK) void k_vertex(const DrawParams* __restrict__ draws,
                                                 const BlockMap* __restrict__ blocks,
                                                 VOut* __restrict__ vout, const uint32_t* __restrict__ visible,
                                                 float* __restrict__ fog_r1_of_draw0 /* &draws[0].fog_r1: it and fog_den are written, never read here */,
@@ -223,7 +223,7 @@ __device__ __forceinline__ int setup_triangle(const FrameParams& fp, int cull, u
 // its clipped polygon), slot 2*t+1 the second fan triangle.  Wireframe: six slots per triangle, three DrawLine
 // edges per fan triangle, in the reference's call order.  Slots keep submission order, which the per-tile lists preserve.
 #define SWR_FRAG_DRAW(dp, bm) ((dp)->frag_draw)
-__global__ __launch_bounds__(SWR_GEOM_BLOCK) SWR_FRONT_VGPRS void k_setup(const DrawParams* __restrict__ draws,
+__global__ __launch_bounds__(SWR_GEOM_BLOCK) void k_setup(const DrawParams* __restrict__ draws,
                                                const BlockMap* __restrict__ blocks,
                                                const VOut* __restrict__ vout_ro,
                                                VOut* __restrict__ clip_pool,     // 4 VOut per triangle, indexed by global triangle

@@ -107,7 +107,7 @@ struct CoverArgs {
 #define SWR_COVER_WQ 4
 // LINES: the batch is DebugMode.Wireframe (DrawLine records); compiled out of the filled-triangle instantiation
 template <bool LINES>
-__global__ __launch_bounds__(SWR_COVER_BLOCK) SWR_FRONT_VGPRS void k_cover(CoverArgs a) {
+__global__ __launch_bounds__(SWR_COVER_BLOCK) void k_cover(CoverArgs a) {
     SWR_FRONT_ENTER();
     constexpr int CB = SWR_COVER_BLOCK;
     constexpr int NB = 1 + (16 / SWR_COVER_HQ) * (16 / SWR_COVER_WQ);
