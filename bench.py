@@ -436,7 +436,8 @@ def main():
             written_local = st["fragments_written"] / args.steps
             achieved = written_local * BYTES_PER_WRITTEN_FRAGMENT / (raster_ms * 1e-3) / 1e9
             frame_bytes = (W * H if not dist_on else color_t[0].shape[0] * W) * 20.0
-            traffic, traffic_detail = pmc_traffic(args.config, world)
+            # (the committed PMC passes are of the nearest-filter frame: the bilinear one has no traffic figure)
+            traffic, traffic_detail = pmc_traffic(args.config, world) if not getattr(args, "bilinear", False) else (None, None)
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_raster_c",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -473,7 +474,7 @@ def main():
                     out["roofline"]["warning"] = (f"the timed region's kernel samples and the one-stream kernel_ms differ by {100 * rel:.1f} %"
                                                   + (": expected with frames in flight (the kernel shares the chip with the next frame's front end)"
                                                      if args.pipelining else ": measurement noise above 3 %"))
-            vf = valu_floor(args.config, world, raster_ms, written_local)
+            vf = valu_floor(args.config, world, raster_ms, written_local) if not getattr(args, "bilinear", False) else None
             if vf is not None:
                 out["roofline"]["valu_floor"] = vf
         if isolated is not None:
