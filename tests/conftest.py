@@ -10,6 +10,16 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # children of the GPU tests are started by a helper that exists before any test touches the GPU (tests/spawner.py)
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        import spawner
+        spawner.start()
+
+
+def pytest_unconfigure(config):
+    import spawner
+    spawner.stop()
 
 
 @pytest.fixture(scope="session")

@@ -6,11 +6,12 @@ and `bench.py --fake-world`; a multi-GPU node is the driver's to run."""
 import json
 import os
 import socket
-import subprocess
 import sys
 
 import numpy as np
 import pytest
+
+import spawner
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,7 +31,7 @@ def test_two_ranks_on_one_gpu_store_their_bands_into_rank0s_frame(tmp_path):
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg3_small", "--steps", "3",
            "--warmup", "1", "--prime", "2", "--gather", "p2p", "--backend", "gloo", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = spawner.run(cmd, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["multi_gpu"]["gather_payload"] == "p2p" and line["multi_gpu"]["frames_resent_after_replay"] == 0
@@ -64,7 +65,7 @@ def test_the_rccl_leg_runs_end_to_end_with_one_rank(tmp_path, gather):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--config", "cfg3_small", "--steps", "5",
            "--warmup", "2", "--prime", "3", "--gather", gather, "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = spawner.run(cmd, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["multi_gpu"]["forced_one_rank_rehearsal"] is True
