@@ -430,18 +430,38 @@ struct __attribute__((aligned(16))) WaveLdsC {
 #endif
 
 // n steps of the reference's incremental edge chain (Rasterizer.cs:527-534) for this lane, 0 <= n <= MAXN: exactly n float additions per
-// edge, in order.  As a per-lane loop (`for (i < n)`) this was three adds, a compare, two exec updates and a TAKEN branch per
-// iteration, ~10 iterations per chunk: 1,219 of a chunk's 4,229 wave ticks went into the replay (tools/phase_times.py, round 4) --
-// branch latency, not arithmetic.  Here the steps are predicated (a lane that is done just sits out the add) and only every fourth
-// step asks the WAVE whether anybody still has steps left: one forward branch, taken once.
+// edge, in order.  History: as a per-lane loop (`for (i < n)`) this was three adds, a compare, two exec updates and a TAKEN branch per
+// iteration; as predicated C++ (`if (i < n) w += s`, round 4) the compiler if-converts every step into three adds, a compare and THREE
+// v_cndmask -- and a v_cndmask fed by vcc is the most expensive vector instruction this kernel issues (tools/ubench/valu_rate.hip: 23
+// cycles per wave-instruction against 2.5 for the add; profiles/r04_valu_issue_model.md): ~33 of them per chunk.  Here the predicate
+// lives where the hardware keeps predicates: each step narrows EXEC with one v_cmpx (the lanes with steps left only ever become fewer),
+// the adds run under it, every fourth step leaves when no lane is left, and EXEC is restored at the end -- inside ONE asm statement, so
+// the compiler never sees EXEC change.  Operand order of the adds as the compiler had it (step first).
+#define SWR_RP_STEP(I) "v_cmpx_lt_i32_e32 vcc, " #I ", %[n]\n v_add_f32_e32 %[w0], %[s0], %[w0]\n v_add_f32_e32 %[w1], %[s1], %[w1]\n v_add_f32_e32 %[w2], %[s2], %[w2]\n"
+#define SWR_RP_OUT "s_nop 4\n s_cbranch_execz .Lrp_end_%=\n"       /* (wait states between the VALU write of EXEC and the branch on EXECZ: insurance, 3 per column replay) */
 template <int MAXN>
 __device__ __forceinline__ void replay_chain(float& w0, float& w1, float& w2, int n, float s0, float s1, float s2) {
-#pragma unroll
-    for (int g = 0; g < MAXN; g += 4) {
-        if (SWR_BALLOT(n > g) == 0ull) break;                    // wave-uniform
-#pragma unroll
-        for (int i = g; i < g + 4 && i < MAXN; ++i)
-            if (i < n) { w0 += s0; w1 += s1; w2 += s2; }
+    static_assert(MAXN == 3 || MAXN == 7 || MAXN == 15, "row replay (RT_ROWS - 1) or column replay (15)");
+    unsigned long long saved;
+    if constexpr (MAXN == 3) {
+        asm("s_mov_b64 %[sv], exec\n"
+            SWR_RP_STEP(0) SWR_RP_STEP(1) SWR_RP_STEP(2)
+            "s_mov_b64 exec, %[sv]"
+            : [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [sv] "=&s"(saved) : [n] "v"(n), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2) : "vcc");
+    } else if constexpr (MAXN == 7) {
+        asm("s_mov_b64 %[sv], exec\n"
+            SWR_RP_STEP(0) SWR_RP_STEP(1) SWR_RP_STEP(2) SWR_RP_STEP(3) SWR_RP_OUT
+            SWR_RP_STEP(4) SWR_RP_STEP(5) SWR_RP_STEP(6)
+            ".Lrp_end_%=:\n s_mov_b64 exec, %[sv]"
+            : [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [sv] "=&s"(saved) : [n] "v"(n), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2) : "vcc");
+    } else {
+        asm("s_mov_b64 %[sv], exec\n"
+            SWR_RP_STEP(0) SWR_RP_STEP(1) SWR_RP_STEP(2) SWR_RP_STEP(3) SWR_RP_OUT
+            SWR_RP_STEP(4) SWR_RP_STEP(5) SWR_RP_STEP(6) SWR_RP_STEP(7) SWR_RP_OUT
+            SWR_RP_STEP(8) SWR_RP_STEP(9) SWR_RP_STEP(10) SWR_RP_STEP(11) SWR_RP_OUT
+            SWR_RP_STEP(12) SWR_RP_STEP(13) SWR_RP_STEP(14)
+            ".Lrp_end_%=:\n s_mov_b64 exec, %[sv]"
+            : [w0] "+v"(w0), [w1] "+v"(w1), [w2] "+v"(w2), [sv] "=&s"(saved) : [n] "v"(n), [s0] "v"(s0), [s1] "v"(s1), [s2] "v"(s2) : "vcc");
     }
 }
 
