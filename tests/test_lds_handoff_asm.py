@@ -98,3 +98,31 @@ def test_k_cover_hand_off_is_fenced(kernels):
         # the compiler leaves its `; wave barrier` marker where the fence stood
         assert any("wave barrier" in ln for ln in tail[:rd]), f"{name}: no wave barrier between the atomic max and the read"
         assert any("v_readfirstlane_b32" in ln for ln in tail[rd:rd + 12]), name
+
+
+def test_chain_replay_keeps_its_predicate_in_exec(kernels):
+    """replay_chain (swr_raster_c.hip.h): one v_cmpx per step narrows EXEC, the three adds run under it, EXEC is saved before the first
+    step and restored after the last inside the same asm statement.  As predicated C++ the compiler if-converted every step into three
+    adds, a compare and three v_cndmask (profiles/r04_valu_issue_model.md); this keeps the shape from coming back unnoticed."""
+    for name, (lines, lds) in kernels.items():
+        if "k_raster_c" not in name:
+            continue
+        blocks, cur = [], None
+        for ln in lines:
+            if "#ASMSTART" in ln:
+                cur = []
+            elif "#ASMEND" in ln:
+                if cur is not None and any("v_cmpx_lt_i32" in x for x in cur):
+                    blocks.append(cur)
+                cur = None
+            elif cur is not None:
+                cur.append(ln)
+        # a row replay (3 steps with staged varyings, 7 with the varyings in HBM) and a column replay (15 steps) per instantiation
+        steps = sorted(sum("v_cmpx_lt_i32" in x for x in b) for b in blocks)
+        assert steps in ([3, 15], [7, 15]), (name, steps)
+        for b in blocks:
+            body = [x.strip() for x in b if x.strip()]
+            assert body[0].startswith("s_mov_b64") and body[0].endswith("exec"), (name, body[0])          # save
+            assert body[-1].startswith("s_mov_b64 exec,"), (name, body[-1])                              # restore
+            assert sum(x.startswith("v_add_f32") for x in body) == 3 * sum("v_cmpx_lt_i32" in x for x in body), name
+            assert not any("v_cndmask" in x for x in body), name
